@@ -1,0 +1,554 @@
+// figbird_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// A sequential CPU restatement of the gap-fill hot path of SumitTarafder/Figbird
+// (what FillGaps.cpp dispatches: Figbird.cpp main()'s per-gap loop -> GapFiller::fillGap),
+// written from a reading of the reference, each function citing the reference file:line
+// it follows.  It exists only so that tests/, __graft_entry__.smoke() and bench.py's
+// cpu_baseline leg can check / time the HIP path against it.  The product (figbird_amd/,
+// libfighip.so, figfill) never includes, links or executes anything in this directory.
+//
+// Pinning: the reference has no tests or golden vectors of its own.  This
+// restatement is pinned against the reference's own binaries (oracle/_ref, built by
+// oracle/Makefile from /root/reference where it lies) on seeded synthetic inputs:
+// byte-identical gapout / gaptofill / filledContigs.fa / Ncount.txt.  See tests/golden/.
+//
+// It deliberately reproduces the reference's quirks: uninitialised-
+// but-unused values, off-by-one read caps, float candidate ranges, stale strings, etc.
+//
+// Usage (same positional arguments as the reference programs):
+//   figbird_oracle figbird  <16 args of Figbird.cpp main, Figbird.cpp:6957-6973>
+//   figbird_oracle fillgaps <15 args of FillGaps.cpp main, FillGaps.cpp:419-433>
+// Env: FIG_ORACLE_TRACE=<file> FIG_ORACLE_TRACE_LEVEL=1|2|3 -> per-candidate / per-iteration
+//      numeric planes (hex floats) used as kernel-parity fixtures.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using std::string;
+using std::vector;
+
+namespace {
+
+const int MAX_REC_LEN = 1024;       // Figbird.cpp:17
+const int MAX_READLENGTH = 200;     // Figbird.cpp:18
+const int MAX_GAP = 100000;         // Figbird.cpp:30
+const int partial_limit = 3000;     // Figbird.cpp:114
+const int unmapped_limit = 3000;    // Figbird.cpp:115
+const int windowSize = 12;          // Figbird.cpp:89
+
+FILE *g_trace = nullptr;
+int g_trace_level = 0;
+long g_place_calls = 0;
+double g_flops = 0;                 // algorithmic FP64 flops (SURVEY.md §8d formula)
+
+// ---------------------------------------------------------------- scaffold -------------
+struct Scaffolds {
+    vector<string> names;
+    vector<string> seq;             // upper-cased
+};
+
+// Figbird.cpp:6979-7058 / FillGaps.cpp:708-788: header = first whitespace token, ';' lines
+// skipped, sequence lines concatenated; a final line without '\n' loses its last character
+// (`line[read-1]='\0'`, Figbird.cpp:7030,7037).
+static bool load_scaffolds(const char *path, Scaffolds &sc) {
+    FILE *f = fopen(path, "r");
+    if (!f) return false;
+    string cur;
+    bool have = false;
+    char *line = nullptr;
+    size_t cap = 0;
+    ssize_t n;
+    string pending_name;
+    long curlen = 0;
+    while ((n = getline(&line, &cap, f)) != -1) {
+        if (line[0] == ';') continue;
+        if (line[0] == '>') {
+            string nm(line + 1);
+            if (!nm.empty()) nm.pop_back();                 // contigName[strlen-1]='\0'
+            size_t b = nm.find_first_not_of(" \t\n");
+            size_t e = (b == string::npos) ? string::npos : nm.find_first_of(" \t\n", b);
+            string tok = (b == string::npos) ? string() : nm.substr(b, e == string::npos ? string::npos : e - b);
+            sc.names.push_back(tok);
+            if (curlen > 0) {                               // Figbird.cpp:6999
+                sc.seq.push_back(cur);
+                cur.clear();
+                curlen = 0;
+            }
+            have = true;
+        } else {
+            string s(line, (size_t)n);
+            if (!s.empty()) s.pop_back();                   // drops '\n' (or the last base)
+            cur += s;
+            curlen += (long)s.size();
+        }
+    }
+    free(line);
+    fclose(f);
+    (void)have;
+    sc.seq.push_back(cur);                                  // Figbird.cpp:7043-7046
+    for (auto &s : sc.seq)
+        for (auto &c : s) c = (char)toupper((unsigned char)c);
+    return true;
+}
+
+int charCodes[256];
+static void init_char_codes() {                             // Figbird.cpp:7060-7082
+    for (int i = 0; i < 256; i++) charCodes[i] = 4;
+    charCodes['A'] = 0; charCodes['C'] = 1; charCodes['G'] = 2; charCodes['T'] = 3;
+}
+static inline int cc(char c) { return charCodes[(unsigned char)c]; }
+
+// ---------------------------------------------------------------- model (A0) -----------
+struct Model {
+    int maxReadLength = 0;
+    int MAX_INSERT_SIZE = 0;
+    int maxInsertSize = 0;
+    long totalCount = 0, unCount = 0;
+    vector<long> insertCounts;
+    long errorTypes[5][5];
+    long baseCounts[5];
+    vector<long> errorPos, inPos, inLengths, delPos, delLengths, readLengths;
+    double errorTypeProbs[5][5];
+    double baseErrorRates[5];
+    vector<double> errorPosDist, inPosDist, inLengthDist, delPosDist, delLengthDist;
+    vector<double> insertLengthDist, insertLengthDistSmoothed, noErrorProbs;
+    vector<long> effectiveLengths, insertCountsMapped;
+    double insertSizeMean = 0, insertSizeVar = 0, insertSizeSD = 0, leftSD = 0, rightSD = 0;
+    int insertSizeMode = 0, insertCutoffMax = 0, insertCutoffMin = 0;
+    int insertThresholdMax = 0, insertThresholdMin = 0, insertCountMax = 0;
+    long discardedReads = 0, erroredReads = 0, uniqueMappedReads = 0;
+    long gapProbs[1000];
+    int gapProbCutOff = 0;
+    double inputMean = 0;
+    string noErrorCigar, noErrorMD;
+    vector<long> contigLengths;
+};
+Model M;
+
+static void initInsertCounts(int mx) {                      // Figbird.cpp:176-184
+    M.maxInsertSize = mx;
+    M.insertCounts.assign(mx, 1);
+}
+
+static void updateInsertCounts(int index) {                 // Figbird.cpp:186-225
+    if (index <= 0) return;
+    if (index < M.maxInsertSize) { M.insertCounts[index]++; return; }
+    if (index > M.MAX_INSERT_SIZE) { M.discardedReads++; return; }
+    int t = std::max(M.maxInsertSize * 2, index);
+    // NB the reference allocates max(2*old,index) slots and then writes [index]; with
+    // index == t that is one past the end.  MAX_INSERT_SIZE >= 20000 == initial size, so
+    // this branch needs index in [20000, MAX_INSERT_SIZE]; keep it memory-safe here.
+    M.insertCounts.resize((size_t)t + 1, 1);
+    M.insertCounts[index]++;
+    M.maxInsertSize = t;
+}
+
+static void initErrorTypes(int readLength) {                // Figbird.cpp:227-252
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) M.errorTypes[i][j] = 1;
+    for (int i = 0; i < 5; i++) M.baseCounts[i] = 1;
+    M.errorPos.assign(readLength, 1); M.inPos.assign(readLength, 1);
+    M.inLengths.assign(readLength, 1); M.delPos.assign(readLength, 1);
+    M.delLengths.assign(readLength, 1); M.readLengths.assign(readLength, 0);
+}
+
+static int base5(char c) {
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+// Figbird.cpp:291-487.  `md` is the full "MD:Z:..." token, `read` the SAM sequence.
+static void processErrorTypes(const char *cigar, const char *md, const char *read, int strandNo) {
+    int readLength = 0;                                     // getLength, Figbird.cpp:255-275
+    for (; read[readLength]; readLength++) M.baseCounts[base5(read[readLength])]++;
+    M.readLengths[readLength - 1]++;
+    if (strcmp(md, M.noErrorCigar.c_str()) != 0) M.erroredReads++; else return;   // :297 (quirk 5)
+
+    unsigned long mdLength = strlen(md) - 5;
+    vector<int> inserts(readLength, 0);
+    int index = 0, totalLength = 0, curIndex = 0;
+    unsigned long tempLength = 0;
+    {
+        vector<char> tc(cigar, cigar + strlen(cigar) + 1);
+        char *temp = strtok(tc.data(), "IDMS^\t\n ");
+        while (temp != NULL) {
+            tempLength = atoi(temp);
+            totalLength += (int)strlen(temp);
+            char cigarChar = cigar[totalLength];
+            if (cigarChar == 'M') { index += tempLength; curIndex += tempLength; }
+            else if (cigarChar == 'I' || cigarChar == 'S') {
+                if (strandNo == 0) { M.inPos[index]++; M.inLengths[tempLength - 1]++; }
+                else { M.inPos[readLength - index - 1]++; M.inLengths[tempLength - 1]++; }
+                inserts[curIndex] = (int)tempLength;
+                index += tempLength;
+            } else if (cigarChar == 'D') {
+                if (strandNo == 0) { M.delPos[index]++; M.delLengths[tempLength - 1]++; }
+                else { M.delPos[readLength - index - 1]++; M.delLengths[tempLength - 1]++; }
+            }
+            totalLength++;
+            temp = strtok(NULL, "IDMS^\t\n ");
+        }
+    }
+    vector<char> tm(md, md + strlen(md) + 1);
+    strtok(tm.data(), ":");
+    strtok(NULL, ":");
+    index = 0; totalLength = 0; tempLength = 0;
+    char *temp;
+    while ((temp = strtok(NULL, "ACGTN^\t\n ")) != NULL) {
+        tempLength = strlen(temp);
+        totalLength += (int)tempLength;
+        if ((unsigned long)totalLength < mdLength) {
+            char from = md[5 + totalLength];
+            if (from == '^') {
+                totalLength++;
+                index += atoi(temp);
+                for (unsigned long i = totalLength; i < mdLength; i++) {
+                    from = md[5 + totalLength];
+                    if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') totalLength++;
+                    else break;
+                }
+            } else if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') {
+                totalLength++;
+                index += atoi(temp) + 1;
+                curIndex = 0;
+                for (int i = 0; i < index; i++) curIndex += inserts[i];
+                char to = read[index - 1 + curIndex];
+                if (strandNo == 0) M.errorPos[index - 1 + curIndex]++;
+                else M.errorPos[readLength - index - curIndex]++;
+                int f = base5(from), t = base5(to);
+                if (f != t) M.errorTypes[f][t]++;
+            } else break;
+        }
+    }
+}
+
+struct SamRec {                                             // the columns Figbird.cpp reads
+    string qname; int flag = 0; string rname; int pos = 0; string cigar; int tlen = 0;
+    string seq; string md; int nh = 0; bool has_md = false, has_nh = false;
+};
+
+static bool parse_sam10(char *line, SamRec &r) {            // Figbird.cpp:864-901 token order
+    char *save = nullptr;
+    char *t = strtok_r(line, "\t", &save); if (!t) return false; r.qname = t;
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.flag = atoi(t);
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.rname = t;
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.pos = atoi(t);
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.cigar = t;
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.tlen = atoi(t);
+    t = strtok_r(NULL, "\t", &save); if (!t) return false; r.seq = t;
+    while ((t = strtok_r(NULL, "\t\n", &save)) != NULL) {
+        if (t[0] == 'M' && t[1] == 'D') { r.md = t; r.has_md = true; }
+        else if (t[0] == 'I' && t[1] == 'H') { r.nh = atoi(t + 5); r.has_nh = true; }
+    }
+    return true;
+}
+
+static void processMapping(char *line) {                    // Figbird.cpp:846-921
+    SamRec r;
+    if (!parse_sam10(line, r)) return;
+    int strandNo = (r.flag & 16) >> 4;
+    if (r.nh == 1 && r.md.size() > 5 && r.md[5] != '^') {
+        long contigNo = atol(r.rname.c_str());              // getContigNo, :277-281
+        if ((double)M.contigLengths[contigNo] > M.inputMean) updateInsertCounts(r.tlen);  // isGaussian==0
+        processErrorTypes(r.cigar.c_str(), r.md.c_str(), r.seq.c_str(), strandNo);
+        M.uniqueMappedReads++;
+    }
+}
+
+static void computeProbabilites() {                         // Figbird.cpp:497-844
+    int errorCount = 0;
+    for (int i = 0; i < 5; i++) {
+        errorCount = 0;
+        for (int j = 0; j < 5; j++) errorCount += (int)M.errorTypes[i][j];
+        for (int j = 0; j < 5; j++) M.errorTypeProbs[i][j] = (double)M.errorTypes[i][j] / errorCount;
+        M.baseErrorRates[i] = errorCount / (double)M.baseCounts[i];
+    }
+    double sum = 0;
+    for (int i = 0; i < 4; i++) sum += M.baseErrorRates[i];
+    for (int i = 0; i < 4; i++) M.baseErrorRates[i] = 4 * M.baseErrorRates[i] / sum;
+    M.baseErrorRates[4] = 1;
+    int L = M.maxReadLength;
+    for (int i = L - 1; i > 0; i--) M.readLengths[i - 1] = M.readLengths[i] + M.readLengths[i - 1];
+    M.errorPosDist.resize(L); M.inPosDist.resize(L); M.inLengthDist.resize(L);
+    M.delPosDist.resize(L); M.delLengthDist.resize(L);
+    for (int i = 0; i < L; i++) M.errorPosDist[i] = (double)M.errorPos[i] / M.readLengths[i];
+    for (int i = 0; i < L; i++) M.inPosDist[i] = (double)M.inPos[i] / M.readLengths[i];
+    int inCount = 0;
+    for (int i = 0; i < L; i++) inCount += (int)M.inLengths[i];
+    for (int i = 0; i < L; i++) M.inLengthDist[i] = (double)M.inLengths[i] / inCount;
+    for (int i = 0; i < L; i++) M.delPosDist[i] = (double)M.delPos[i] / M.readLengths[i];
+    int delCount = 0;
+    for (int i = 0; i < L; i++) delCount += (int)M.delLengths[i];
+    for (int i = 0; i < L; i++) M.delLengthDist[i] = (double)M.delLengths[i] / delCount;
+
+    int mis = M.maxInsertSize;
+    M.insertLengthDist.resize(mis);
+    long insCount = M.discardedReads;
+    sum = 0;
+    for (int i = 0; i < mis; i++) { insCount += (M.insertCounts[i] - 1); sum += i * (M.insertCounts[i] - 1); }
+    M.insertSizeMean = sum / insCount;
+    sum = 0;
+    for (int i = 0; i < mis; i++) {
+        M.insertLengthDist[i] = (double)M.insertCounts[i] / insCount;
+        sum += (M.insertCounts[i] - 1) * (M.insertSizeMean - i) * (M.insertSizeMean - i);
+    }
+    M.insertSizeVar = sum / insCount;
+    M.insertSizeSD = sqrt(M.insertSizeVar);
+    M.noErrorProbs.resize(L);
+    double noErrorProb = 1.0;
+    for (int i = 0; i < L; i++) {
+        noErrorProb *= (1 - M.errorPosDist[i] - M.inPosDist[i] - M.delPosDist[i]);
+        M.noErrorProbs[i] = noErrorProb;
+    }
+    M.effectiveLengths.assign(mis, -1);
+    long totalContigLength = 0;
+    for (size_t i = 0; i < M.contigLengths.size(); i++) totalContigLength += M.contigLengths[i];
+    M.effectiveLengths[0] = totalContigLength;
+    M.insertCountsMapped.assign(mis, 0);
+
+    M.insertLengthDistSmoothed.resize(mis);
+    double windowSum = 0;
+    for (int i = 0; i < windowSize; i++) M.insertLengthDistSmoothed[i] = M.insertLengthDist[i];
+    for (int i = 0; i < 2 * windowSize + 1; i++) windowSum += M.insertLengthDist[i];
+    M.insertLengthDistSmoothed[windowSize] = windowSum / (2 * windowSize + 1);
+    for (int i = windowSize + 1; i < mis - windowSize; i++) {
+        windowSum -= M.insertLengthDist[i - windowSize - 1];
+        windowSum += M.insertLengthDist[i + windowSize];
+        M.insertLengthDistSmoothed[i] = windowSum / (2 * windowSize + 1);
+    }
+    for (int i = mis - windowSize; i < mis; i++) M.insertLengthDistSmoothed[i] = M.insertLengthDist[i];
+    for (int i = 0; i < mis; i++)
+        M.insertLengthDistSmoothed[i] = M.insertLengthDistSmoothed[i] - 1 / (double)(insCount) +
+                                        (1 / (double)mis) / (double)(insCount + 1);
+
+    int count = 0;
+    for (int i = (int)M.insertSizeMean; i < mis; i++) {
+        if (M.insertCounts[i] <= 1) { count++; if (count == 10) { M.insertCutoffMax = i; break; } }
+        else count = 0;
+    }
+    count = 0;
+    for (int i = (int)M.insertSizeMean; i >= 0; i--) {
+        if (M.insertCounts[i] <= 1) { count++; if (count == 10) { M.insertCutoffMin = i; break; } }
+        else count = 0;
+    }
+    M.insertCountMax = 0;
+    for (int i = 0; i < mis; i++)
+        if (M.insertCounts[i] > M.insertCountMax) { M.insertCountMax = (int)M.insertCounts[i]; M.insertSizeMode = i; }
+    count = 0;
+    for (int i = (int)M.insertSizeMean; i < mis; i++) {
+        if (M.insertCounts[i] <= std::max(M.insertCountMax / 1000, 2)) { count++; if (count == 2) { M.insertThresholdMax = i; break; } }
+        else count = 0;
+    }
+    count = 0;
+    for (int i = (int)M.insertSizeMean; i >= 0; i--) {
+        if (M.insertCounts[i] <= std::max(M.insertCountMax / 1000, 2)) { count++; if (count == 2) { M.insertThresholdMin = i; break; } }
+        else count = 0;
+    }
+    double insertSum = 0, insertCount = 0;
+    for (int i = M.insertCutoffMin; i < M.insertCutoffMax; i++) {
+        insertCount += M.insertCounts[i] - 1;
+        insertSum += (M.insertCounts[i] - 1) * i;
+    }
+    M.insertSizeMode = (int)(insertSum / insertCount);
+    insertSum = 0; insertCount = 0;
+    for (int i = (int)(M.insertSizeMean + 1); i < mis; i++) {
+        insertSum = insertSum + (M.insertCounts[i] - 1) * (i - M.insertSizeMean) * (i - M.insertSizeMean);
+        insertCount += (M.insertCounts[i] - 1);
+    }
+    M.rightSD = sqrt(insertSum / insertCount);
+    insertSum = 0; insertCount = 0;
+    for (int i = std::max((int)(M.insertSizeMean - 10 * M.rightSD), 0); i < M.insertSizeMean; i++) {
+        insertSum = insertSum + (M.insertCounts[i] - 1) * (M.insertSizeMean - i) * (M.insertSizeMean - i);
+        insertCount += (M.insertCounts[i] - 1);
+    }
+    M.leftSD = sqrt(insertSum / insertCount);
+    M.insertCutoffMax = M.insertThresholdMax;
+    M.insertCutoffMin = M.insertThresholdMin;
+}
+
+static long getEffectiveLength(int insertSize) {            // Figbird.cpp:923-950
+    if (insertSize < 0) return M.effectiveLengths[0];
+    if (insertSize >= M.maxInsertSize || M.effectiveLengths[insertSize] == -1) {
+        long e = 0;
+        for (size_t i = 0; i < M.contigLengths.size(); i++)
+            if (M.contigLengths[i] >= insertSize) e += (M.contigLengths[i] - insertSize + 1);
+        if (insertSize >= M.maxInsertSize) return e;
+        M.effectiveLengths[insertSize] = e;
+    }
+    return M.effectiveLengths[insertSize];
+}
+
+// Figbird.cpp:952-1153 (long double, as in the reference).
+static long double computeErrorProb(const char *cigar, const char *md, const char *read, int strandNo) {
+    unsigned long readLength = strlen(read);
+    long double errorProb = M.noErrorProbs[readLength - 1];
+    if (md[5] == '^') return errorProb;
+    unsigned long mdLength = strlen(md) - 5, tempLength = 0;
+    int index = 0, totalLength = 0, curIndex = 0;
+    vector<int> inserts(readLength, 0);
+    {
+        vector<char> tc(cigar, cigar + strlen(cigar) + 1);
+        char *temp = strtok(tc.data(), "IDM^\t\n ");
+        while (temp != NULL) {
+            tempLength = atoi(temp);
+            totalLength += (int)strlen(temp);
+            char cigarChar = cigar[totalLength];
+            if (cigarChar == 'M') { index += tempLength; curIndex += tempLength; }
+            else if (cigarChar == 'I') {
+                unsigned long i = (strandNo == 0) ? (unsigned long)index : readLength - index - 1;
+                errorProb = errorProb * M.inPosDist[i] * M.inLengthDist[tempLength - 1] /
+                            (1 - M.errorPosDist[i] - M.inPosDist[i] - M.delPosDist[i]);
+                inserts[curIndex] = (int)tempLength;
+                index += tempLength;
+            } else if (cigarChar == 'D') {
+                unsigned long i = (strandNo == 0) ? (unsigned long)index : readLength - index - 1;
+                errorProb = errorProb * M.delPosDist[i] * M.delLengthDist[tempLength - 1] /
+                            (1 - M.errorPosDist[i] - M.inPosDist[i] - M.delPosDist[i]);
+            }
+            totalLength++;
+            temp = strtok(NULL, "IDM^\t\n ");
+        }
+    }
+    vector<char> tm(md, md + strlen(md) + 1);
+    strtok(tm.data(), ":");
+    strtok(NULL, ":");
+    index = 0; totalLength = 0; tempLength = 0;
+    char *temp;
+    while ((temp = strtok(NULL, "ACGTN^\t\n ")) != NULL) {
+        tempLength = strlen(temp);
+        totalLength += (int)tempLength;
+        if ((unsigned long)totalLength < mdLength) {
+            char from = md[5 + totalLength];
+            if (from == '^') {
+                totalLength++;
+                index += atoi(temp);
+                for (unsigned long i = totalLength; i < mdLength; i++) {
+                    from = md[5 + totalLength];
+                    if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') totalLength++;
+                    else break;
+                }
+            } else if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') {
+                totalLength++;
+                index += atoi(temp) + 1;
+                curIndex = 0;
+                for (int i = 0; i < index; i++) curIndex += inserts[i];
+                char to = read[index - 1 + curIndex];
+                int i = (strandNo == 0) ? index - 1 + curIndex : (int)readLength - index - curIndex;
+                errorProb = errorProb * M.errorPosDist[i] / (1 - M.errorPosDist[i] - M.inPosDist[i] - M.delPosDist[i]);
+                int f = base5(from), t = base5(to);
+                if (f != t) errorProb *= M.baseErrorRates[f] * M.errorTypeProbs[f][t];
+            } else break;
+        }
+    }
+    return errorProb;
+}
+
+static double computeLikelihood(const char *file) {         // Figbird.cpp:1156-1376
+    FILE *mapFile = fopen(file, "r");
+    char line1[MAX_REC_LEN], line2[MAX_REC_LEN];
+    long double sum = 0.0, logsum = 0.0, gapProb = 0, tempProb = 0;
+    int tempInsertSize = 0;
+    string pre1 = "*", pre2 = "*";
+    while (fgets(line1, MAX_REC_LEN, mapFile) != NULL) {
+        if (line1[0] == '@') continue;
+        if (fgets(line2, MAX_REC_LEN, mapFile) == NULL) break;
+        SamRec a, b;
+        parse_sam10(line1, a);
+        parse_sam10(line2, b);
+        int strandNo1 = (a.flag & 16) >> 4, strandNo2 = (b.flag & 16) >> 4;
+        int insertSize = std::max(a.tlen, b.tlen);
+        long double insertSizeProb = 0;
+        if (insertSize >= 0 && insertSize < M.maxInsertSize) insertSizeProb = M.insertLengthDist[insertSize];
+        if (insertSizeProb == 0) insertSizeProb = 1 / (double)M.uniqueMappedReads;
+        long double errorProb1 = computeErrorProb(a.cigar.c_str(), a.md.c_str(), a.seq.c_str(), strandNo1);
+        long double errorProb2 = computeErrorProb(b.cigar.c_str(), b.md.c_str(), b.seq.c_str(), strandNo2);
+        long totalEffectiveLength = getEffectiveLength(insertSize);
+        long double prob = (1 / (long double)(totalEffectiveLength)) * insertSizeProb * errorProb1 * errorProb2;
+        if (a.qname == pre1 && b.qname == pre2) {
+            if (tempProb < prob) {
+                tempProb = prob; tempInsertSize = insertSize < 0 ? 0 : insertSize; gapProb = errorProb2;
+            }
+            sum += prob;
+        } else if (pre1 != "*" && pre2 != "*") {
+            if (sum < 1e-320 || std::isnan(sum)) sum = 1e-320;
+            logsum += log10l(sum);
+            int gapIndex = (int)(-log10l(gapProb));
+            gapIndex++;
+            if (gapIndex < 1000 && gapIndex >= 0) M.gapProbs[gapIndex]++; else M.gapProbs[999]++;
+            if (tempInsertSize >= M.maxInsertSize) M.insertCountsMapped[M.maxInsertSize - 1]++;
+            else M.insertCountsMapped[tempInsertSize]++;
+            sum = prob; tempProb = prob; tempInsertSize = insertSize < 0 ? 0 : insertSize; gapProb = errorProb2;
+        } else {
+            sum = prob; tempProb = prob; tempInsertSize = insertSize < 0 ? 0 : insertSize; gapProb = errorProb2;
+        }
+        pre1 = a.qname; pre2 = b.qname;
+        if (std::isinf(logsum)) exit(1);
+    }
+    if (sum != 0) {
+        if (sum < 1e-320 || std::isnan(sum)) sum = 1e-320;
+        logsum += log10l(sum);
+    }
+    fclose(mapFile);
+    return (double)logsum;
+}
+
+// Run-level parameters (Figbird.cpp:6957-6973 argv) ------------------------------------
+struct RunArgs {
+    string contigFile; int D = 0; int read_length = 0; int script_itr = 0; int partial_flag = 0;
+    int unmapped = 0; string mapFile, tmp, gapsDir; int neg_lap = 0; int partial_len = 0;
+    int unm_limit = 400; int setinputmean = 0; int isz = 0;
+};
+RunArgs A;
+Scaffolds SC;
+
+static bool build_model() {                                 // Figbird.cpp:7084-7200
+    string p = A.tmp + "stat.txt";
+    FILE *f = fopen(p.c_str(), "r");
+    if (!f) { fprintf(stderr, "oracle: can't open %s\n", p.c_str()); return false; }
+    if (fscanf(f, "%ld %ld %d %d", &M.totalCount, &M.unCount, &M.maxReadLength, &M.MAX_INSERT_SIZE) != 4) { fclose(f); return false; }
+    fclose(f);
+    M.MAX_INSERT_SIZE = M.MAX_INSERT_SIZE > 20000 ? M.MAX_INSERT_SIZE : 20000;
+    M.insertCutoffMin = M.MAX_INSERT_SIZE;
+    initInsertCounts(M.MAX_INSERT_SIZE);
+    initErrorTypes(M.maxReadLength);
+    M.noErrorCigar = std::to_string(M.maxReadLength);
+    M.noErrorMD = "MD:Z:" + M.noErrorCigar;
+    M.noErrorCigar += "M";
+    for (int i = 0; i < 1000; i++) M.gapProbs[i] = 0;
+    M.contigLengths.clear();
+    for (auto &s : SC.seq) M.contigLengths.push_back((long)s.size());
+    if (A.setinputmean == 1) M.inputMean = A.isz;
+
+    FILE *mf = fopen(A.mapFile.c_str(), "r");
+    if (!mf) { printf("Can't open map file\n"); return false; }
+    char line1[MAX_REC_LEN];
+    while (fgets(line1, MAX_REC_LEN, mf) != NULL) {
+        if (line1[0] == '@') continue;
+        processMapping(line1);
+    }
+    fclose(mf);
+    computeProbabilites();
+    computeLikelihood(A.mapFile.c_str());
+    long gapProbSum = 0;
+    for (int i = 0; i < 1000; i++) gapProbSum += M.gapProbs[i];
+    long gapProbCount = 0;
+    double value = .8;
+    for (int i = 0; i < 1000; i++) {
+        gapProbCount += M.gapProbs[i];
+        if (gapProbCount >= value * gapProbSum) { M.gapProbCutOff = i; break; }
+    }
+    double left_coeff = 3, right_coeff = 3;
+    M.insertThresholdMin = std::max((int)(M.insertSizeMean - left_coeff * M.leftSD), 1);
+    M.insertThresholdMax = std::min((int)(M.insertSizeMean + right_coeff * M.rightSD), M.maxInsertSize);
+    if (A.partial_flag) { M.insertThresholdMin -= A.partial_len; M.insertThresholdMax += A.partial_len; }
+    return true;
+}
+
+#include "figbird_oracle_gapfiller.inc"
+
+}  // namespace
+
+int main(int argc, char **argv) { return oracle_main(argc, argv); }
