@@ -1,0 +1,393 @@
+// fig_abi.hip -- libfighip.so: the C ABI of include/figbird_hip.h on top of the gfx950 engine.
+//
+// Host side here = the "packer" role of Figbird.cpp's per-gap loop (Figbird.cpp:7329-7440):
+// findFrac/alloc_arg (:6879-6906, :7393-7400), flank extraction, 2-bit read packing, cost
+// sorting; then persistent-workgroup launches of fig_fill_kernel, one launch per LDS class.
+// There is no CPU compute path in this library.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/figbird_hip.h"
+#include "fig_engine.h"
+#include "fig_pack.h"
+
+// ------------------------------------------------------------------------------------- kernel
+// LDS carve-up (doubles first so everything stays 8-byte aligned):
+//   P[4*capG] Q[5*capG] (if PQ_LDS)  wbuf[capW] (if W_LDS)  FigState  gs[capG]  rb[FIG_MAX_READLEN+8]
+template <bool PQ_LDS, bool W_LDS>
+__global__ void fig_fill_kernel(FigDevModel M, FigDevBatch B, int capG, int capW, int cls, int q_begin, int q_end) {
+    extern __shared__ double fig_lds[];
+    double *lp = fig_lds;
+    FigEng E;
+    E.tid = threadIdx.x; E.nt = blockDim.x;
+    E.M = &M; E.B = &B;
+    E.capG = capG; E.capW = capW; E.flops = 0;
+    unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
+    fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, capW, &E.scr);
+    if (PQ_LDS) { E.P = lp; lp += 4 * (long long)capG; E.Q = lp; lp += 5 * (long long)capG; }
+    else { E.P = E.scr.Pg; E.Q = E.scr.Qg; }
+    if (W_LDS) { E.wbuf = lp; lp += capW; } else E.wbuf = E.scr.wg;
+    E.S = (FigState *)lp;
+    unsigned char *bp = (unsigned char *)(E.S + 1);
+    E.gs = bp; bp += ((capG + 7) & ~7);
+    E.rb = bp;
+    (void)cls;
+    // persistent loop over the class's slice [q_begin, q_end) of the cost-sorted order
+    while (true) {
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        __syncthreads();
+        int qi = q_begin + E.S->bc_i;
+        __syncthreads();
+        if (qi >= q_end) break;
+        E.g = &B.gaps[B.order[qi]];
+        fig_fill_gap(E);
+    }
+    // algorithmic flop count: one atomic per lane at exit
+    if (E.flops) atomicAdd(&B.counters[1], E.flops);
+}
+
+// ------------------------------------------------------------------------------------- context
+#define FIG_HIP(call) do { hipError_t _e = (call); if (_e != hipSuccess) { ctx->last_hip = (int)_e; return FIG_EHIP; } } while (0)
+
+struct DevBuf {
+    void *p = nullptr; size_t n = 0;
+};
+
+struct fig_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int n_cu = 0;
+    int last_hip = 0;
+    bool have_model = false;
+    FigDevModel dm;
+    std::vector<double> h_e, h_ome, h_m3, h_insd, h_qtab;
+    DevBuf d_model_tabs;
+    fig_model hm;
+    // resident batch
+    bool have_batch = false;
+    FigDevBatch db;
+    std::vector<FigDevGap> h_gaps;
+    std::vector<int32_t> h_order;
+    struct Cls { int capG, capW, nt; bool pq_lds, w_lds; size_t lds; int q_begin, q_end; int blocks; };
+    std::vector<Cls> classes;
+    std::vector<DevBuf> bufs;
+    int64_t n_gaps = 0, n_ureads = 0, n_preads = 0, str_total = 0;
+    std::vector<int64_t> h_str_off;
+    fig_stats stats;
+};
+
+static int dev_alloc(fig_ctx *ctx, size_t bytes, void **out) {
+    DevBuf b;
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(&b.p, bytes);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return FIG_ENOMEM; }
+    b.n = bytes;
+    ctx->bufs.push_back(b);
+    *out = b.p;
+    return FIG_OK;
+}
+
+template <typename T>
+static int dev_upload(fig_ctx *ctx, const std::vector<T> &v, const T **out) {
+    void *p = nullptr;
+    int rc = dev_alloc(ctx, v.size() * sizeof(T), &p);
+    if (rc) return rc;
+    if (!v.empty()) {
+        hipError_t e = hipMemcpyAsync(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, ctx->stream);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; return FIG_EHIP; }
+    }
+    *out = (const T *)p;
+    return FIG_OK;
+}
+
+extern "C" int fig_version(void) { return FIG_ABI_VERSION; }
+
+extern "C" const char *fig_strerror(int code) {
+    switch (code) {
+        case FIG_OK: return "ok";
+        case FIG_EINVAL: return "invalid argument";
+        case FIG_ENODEV: return "no usable HIP device (libfighip has no CPU path)";
+        case FIG_ENOMEM: return "out of memory";
+        case FIG_EHIP: return "HIP runtime error";
+        case FIG_ENOSPC: return "result string buffer too small";
+        case FIG_EUNSUP: return "input outside the supported envelope";
+        default: return "unknown error";
+    }
+}
+
+extern "C" int fig_ctx_create(int device_ordinal, fig_ctx **out) {
+    if (!out) return FIG_EINVAL;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FIG_ENODEV;
+    if (device_ordinal < 0 || device_ordinal >= n) return FIG_ENODEV;
+    if (hipSetDevice(device_ordinal) != hipSuccess) return FIG_ENODEV;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_ordinal) != hipSuccess) return FIG_ENODEV;
+    fig_ctx *ctx = new (std::nothrow) fig_ctx();
+    if (!ctx) return FIG_ENOMEM;
+    ctx->device = device_ordinal;
+    ctx->n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (hipStreamCreate(&ctx->stream) != hipSuccess || hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess) {
+        delete ctx;
+        return FIG_EHIP;
+    }
+    memset(&ctx->stats, 0, sizeof(ctx->stats));
+    *out = ctx;
+    return FIG_OK;
+}
+
+static void free_batch(fig_ctx *ctx) {
+    for (auto &b : ctx->bufs) if (b.p) hipFree(b.p);
+    ctx->bufs.clear();
+    ctx->have_batch = false;
+    ctx->classes.clear();
+}
+
+extern "C" void fig_batch_free(fig_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    free_batch(ctx);
+}
+
+extern "C" void fig_ctx_destroy(fig_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    free_batch(ctx);
+    if (ctx->d_model_tabs.p) hipFree(ctx->d_model_tabs.p);
+    if (ctx->ev0) hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) hipEventDestroy(ctx->ev1);
+    if (ctx->stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
+    if (!ctx || !m || !m->error_pos_dist || !m->in_pos_dist || !m->del_pos_dist || !m->insert_len_dist_smoothed) return FIG_EINVAL;
+    if (m->max_read_length <= 0 || m->max_read_length > FIG_MAX_READLEN) return FIG_EUNSUP;
+    if (m->max_insert_size <= 0) return FIG_EINVAL;
+    if (m->partial_flag && m->unmapped_flag) return FIG_EUNSUP;      // the driver never sets both (RunFigbird.sh:211-216)
+    if (m->insert_threshold_min < 0 || m->insert_threshold_max >= m->max_insert_size + 1) return FIG_EINVAL;
+    hipSetDevice(ctx->device);
+    int L = m->max_read_length;
+    ctx->hm = *m;
+    ctx->h_e.assign(m->error_pos_dist, m->error_pos_dist + L);
+    ctx->h_ome.resize(L); ctx->h_m3.resize(L);
+    for (int k = 0; k < L; k++) {
+        volatile double a = 1 - m->error_pos_dist[k];                 // (1-errorPosDist[k])               Figbird.cpp:3160
+        ctx->h_ome[k] = a;
+        volatile double b = 1 - m->error_pos_dist[k] - m->in_pos_dist[k] - m->del_pos_dist[k];   // Figbird.cpp:3400
+        ctx->h_m3[k] = b;
+    }
+    ctx->h_insd.assign(m->insert_len_dist_smoothed, m->insert_len_dist_smoothed + m->max_insert_size);
+    ctx->h_insd.push_back(0.0);                                       // insertThresholdMax may equal maxInsertSize (:7194)
+    ctx->h_qtab.resize(256);
+    for (int c = 0; c < 256; c++) { int Q = c - 33; ctx->h_qtab[c] = pow(10, -Q / 10.0); }   // qualityFilter, :1791-1792
+    size_t nd = (size_t)3 * L + ctx->h_insd.size() + 256;
+    if (ctx->d_model_tabs.p) { hipFree(ctx->d_model_tabs.p); ctx->d_model_tabs.p = nullptr; }
+    if (hipMalloc(&ctx->d_model_tabs.p, nd * sizeof(double)) != hipSuccess) return FIG_ENOMEM;
+    double *d = (double *)ctx->d_model_tabs.p;
+    std::vector<double> all;
+    all.insert(all.end(), ctx->h_e.begin(), ctx->h_e.end());
+    all.insert(all.end(), ctx->h_ome.begin(), ctx->h_ome.end());
+    all.insert(all.end(), ctx->h_m3.begin(), ctx->h_m3.end());
+    all.insert(all.end(), ctx->h_insd.begin(), ctx->h_insd.end());
+    all.insert(all.end(), ctx->h_qtab.begin(), ctx->h_qtab.end());
+    if (hipMemcpy(d, all.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FIG_EHIP;
+    FigDevModel &dm = ctx->dm;
+    dm.L = L; dm.Tmin = m->insert_threshold_min; dm.Tmax = m->insert_threshold_max; dm.cutoff = m->gap_prob_cutoff;
+    dm.partial_flag = m->partial_flag; dm.unmapped = m->unmapped_flag; dm.script_itr = m->script_itr; dm.D = m->max_distance;
+    dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
+    dm.max_insert = m->max_insert_size;
+    for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
+    dm.e = d; dm.ome = d + L; dm.m3 = d + 2 * L; dm.insd = d + 3 * L; dm.qtab = d + 3 * L + ctx->h_insd.size();
+    ctx->have_model = true;
+    return FIG_OK;
+}
+
+extern "C" int64_t fig_results_capacity(const fig_model *m, const fig_gap_batch *b) {
+    if (!m || !b) return FIG_EINVAL;
+    return fig_pack_results_capacity(m, b);
+}
+
+extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
+    if (!ctx || !b) return FIG_EINVAL;
+    if (!ctx->have_model) return FIG_EINVAL;
+    hipSetDevice(ctx->device);
+    free_batch(ctx);
+    const fig_model *m = &ctx->hm;
+    hipEventRecord(ctx->ev0, ctx->stream);
+    FigPacked K;
+    int prc = fig_pack(m, b, sizeof(FigState), K);
+    if (prc) return prc;
+    int64_t ng = K.n_gaps;
+    ctx->h_gaps = K.gaps; ctx->h_order = K.order; ctx->h_str_off = K.str_off;
+    ctx->str_total = K.str_total; ctx->n_gaps = ng;
+    ctx->n_ureads = (int64_t)K.u_pos.size(); ctx->n_preads = (int64_t)K.p_pos.size();
+    ctx->classes.clear();
+    int max_blocks = 1;
+    for (const FigLaunchClass &lc : K.classes) {
+        fig_ctx::Cls c;
+        c.capG = lc.capG; c.capW = lc.capW; c.nt = lc.nt; c.pq_lds = lc.pq_lds; c.w_lds = lc.w_lds; c.lds = lc.lds;
+        c.q_begin = lc.q_begin; c.q_end = lc.q_end;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(c.lds, 1), (size_t)(2048 / c.nt)));
+        per_cu = std::min(per_cu, 8);
+        c.blocks = std::min<int>(c.q_end - c.q_begin, ctx->n_cu * per_cu);
+        max_blocks = std::max(max_blocks, c.blocks);
+        ctx->classes.push_back(c);
+    }
+    int capG_s = K.capG, capW_s = K.capW, capR = K.capR, capP = K.capP, capC = K.capC;
+    int64_t str_total = K.str_total;
+    int64_t stride = fig_scratch_layout(nullptr, capG_s, capR, capP, capC, capW_s, nullptr);
+    stride = (stride + 255) & ~255LL;
+    std::vector<FigDevGap> &gaps = K.gaps; std::vector<int32_t> &order = K.order;
+    std::vector<uint32_t> &packed = K.packed; std::vector<uint8_t> &qual = K.qual, &flank = K.flank;
+    std::vector<int32_t> &u_pos = K.u_pos, &u_aux = K.u_aux, &u_len = K.u_len, &p_pos = K.p_pos, &p_aux = K.p_aux, &p_clip = K.p_clip, &p_ref = K.p_ref, &p_len = K.p_len;
+    std::vector<int64_t> &u_woff = K.u_woff, &p_woff = K.p_woff, &p_qoff = K.p_qoff;
+
+    // ---- upload
+    FigDevBatch &db = ctx->db;
+    memset(&db, 0, sizeof(db));
+    db.n_gaps = ng;
+    int rc;
+#define UP(vec, field) do { rc = dev_upload(ctx, vec, &db.field); if (rc) return rc; } while (0)
+    UP(gaps, gaps); UP(order, order); UP(packed, packed); UP(qual, qual); UP(flank, flank);
+    UP(u_pos, u.pos); UP(u_aux, u.aux); UP(u_len, u.len); UP(u_woff, u.woff);
+    UP(p_pos, p.pos); UP(p_aux, p.aux); UP(p_clip, p.clip); UP(p_ref, p.refpos); UP(p_len, p.len); UP(p_woff, p.woff); UP(p_qoff, p.qoff);
+#undef UP
+    db.u.clip = nullptr; db.u.refpos = nullptr; db.u.qoff = nullptr;
+    void *p;
+    if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.filled_len = (int32_t *)p;
+    if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
+    if ((rc = dev_alloc(ctx, (size_t)str_total, &p))) return rc; db.str = (char *)p;
+    if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.queue_head = (int32_t *)p;
+    if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.counters = (unsigned long long *)p;
+    if ((rc = dev_alloc(ctx, (size_t)stride * max_blocks, &p))) return rc; db.scratch = (uint8_t *)p;
+    db.scratch_stride = stride;
+    db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC;
+    db.n_ureads = ctx->n_ureads;
+    FIG_HIP(hipMemsetAsync(db.counters, 0, 64, ctx->stream));
+    hipEventRecord(ctx->ev1, ctx->stream);
+    FIG_HIP(hipStreamSynchronize(ctx->stream));
+    float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->stats.h2d_ms = ms;
+    ctx->stats.packed_bytes = K.packed_bytes();
+    ctx->have_batch = true;
+    return FIG_OK;
+}
+
+template <bool PQ, bool W>
+static hipError_t launch_cls(fig_ctx *ctx, const fig_ctx::Cls &c, int ci) {
+    auto k = fig_fill_kernel<PQ, W>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3(c.blocks), dim3(c.nt), c.lds, ctx->stream, ctx->dm, ctx->db, c.capG, c.capW, ci, c.q_begin, c.q_end);
+    return hipGetLastError();
+}
+
+extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
+    if (!ctx || !out || !ctx->have_batch) return FIG_EINVAL;
+    if (!out->filled_len || !out->gaptofill || !out->str_off || (!out->str && ctx->str_total > 0)) return FIG_EINVAL;
+    hipSetDevice(ctx->device);
+    int64_t ng = ctx->n_gaps;
+    FigDevBatch &db = ctx->db;
+    // optional debug / draw planes live in per-call device buffers
+    std::vector<void *> tmp;
+    auto talloc = [&](size_t n, void **p) -> int { if (hipMalloc(p, n ? n : 8) != hipSuccess) return FIG_ENOMEM; tmp.push_back(*p); return FIG_OK; };
+    auto tfree = [&]() { for (void *p : tmp) hipFree(p); };
+    db.dbg_n_cand = nullptr; db.dbg_cand_i = nullptr; db.dbg_cand_lik = nullptr; db.dbg_max_cand = 0;
+    db.draw_pos = db.draw_isz = db.draw_len = nullptr;
+    void *p;
+    if (out->dbg_n_cand && out->dbg_cand_i && out->dbg_cand_lik && out->dbg_max_cand > 0) {
+        db.dbg_max_cand = out->dbg_max_cand;
+        if (talloc((size_t)ng * 4, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_n_cand = (int32_t *)p;
+        if (talloc((size_t)ng * out->dbg_max_cand * 12, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_cand_i = (int32_t *)p;
+        if (talloc((size_t)ng * out->dbg_max_cand * 8, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_cand_lik = (double *)p;
+        hipMemsetAsync(db.dbg_n_cand, 0, (size_t)ng * 4, ctx->stream);
+    }
+    int64_t nr = ctx->n_ureads + ctx->n_preads;
+    if (out->draw_pos && out->draw_isz && out->draw_len) {
+        if (talloc((size_t)nr * 4, &p)) { tfree(); return FIG_ENOMEM; } db.draw_pos = (int32_t *)p;
+        if (talloc((size_t)nr * 4, &p)) { tfree(); return FIG_ENOMEM; } db.draw_isz = (int32_t *)p;
+        if (talloc((size_t)ng * 8, &p)) { tfree(); return FIG_ENOMEM; } db.draw_len = (int32_t *)p;
+        hipMemsetAsync(db.draw_isz, 0, (size_t)nr * 4, ctx->stream);
+    }
+    hipMemsetAsync(db.counters, 0, 64, ctx->stream);
+    hipMemsetAsync(db.str, 'N', (size_t)ctx->str_total, ctx->stream);
+    hipEventRecord(ctx->ev0, ctx->stream);
+    int nl = 0;
+    for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
+        const fig_ctx::Cls &c = ctx->classes[ci];
+        hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
+        hipError_t e;
+        if (c.pq_lds && c.w_lds) e = launch_cls<true, true>(ctx, c, (int)ci);
+        else if (c.pq_lds) e = launch_cls<true, false>(ctx, c, (int)ci);
+        else e = launch_cls<false, false>(ctx, c, (int)ci);
+        if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
+        nl++;
+    }
+    hipEventRecord(ctx->ev1, ctx->stream);
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
+    float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->stats.kernel_ms = ms; ctx->stats.n_launches = nl;
+    // ---- results back
+    hipEventRecord(ctx->ev0, ctx->stream);
+    std::vector<char> hstr((size_t)ctx->str_total);
+    hipMemcpyAsync(out->filled_len, db.filled_len, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+    hipMemcpyAsync(out->gaptofill, db.gaptofill, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (ctx->str_total) hipMemcpyAsync(hstr.data(), db.str, (size_t)ctx->str_total, hipMemcpyDeviceToHost, ctx->stream);
+    unsigned long long cnt[8] = {0};
+    hipMemcpyAsync(cnt, db.counters, 64, hipMemcpyDeviceToHost, ctx->stream);
+    if (db.dbg_n_cand) {
+        hipMemcpyAsync(out->dbg_n_cand, db.dbg_n_cand, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(out->dbg_cand_i, db.dbg_cand_i, (size_t)ng * out->dbg_max_cand * 12, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(out->dbg_cand_lik, db.dbg_cand_lik, (size_t)ng * out->dbg_max_cand * 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    if (db.draw_pos) {
+        hipMemcpyAsync(out->draw_pos, db.draw_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(out->draw_isz, db.draw_isz, (size_t)nr * 4, hipMemcpyDeviceToHost, ctx->stream);
+        hipMemcpyAsync(out->draw_len, db.draw_len, (size_t)ng * 8, hipMemcpyDeviceToHost, ctx->stream);
+    }
+    hipEventRecord(ctx->ev1, ctx->stream);
+    e = hipStreamSynchronize(ctx->stream);
+    tfree();
+    if (e != hipSuccess) { ctx->last_hip = (int)e; return FIG_EHIP; }
+    hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
+    ctx->stats.d2h_ms = ms;
+    ctx->stats.place_calls = (int64_t)cnt[0];
+    ctx->stats.alg_flops = (double)cnt[1];
+    // compact strings
+    int64_t need = 0;
+    for (int64_t g = 0; g < ng; g++) need += out->filled_len[g] > 0 ? out->filled_len[g] : 0;
+    if (need > out->str_capacity) return FIG_ENOSPC;
+    int64_t o = 0;
+    for (int64_t g = 0; g < ng; g++) {
+        out->str_off[g] = o;
+        int n = out->filled_len[g];
+        if (n > 0) { memcpy(out->str + o, hstr.data() + ctx->h_str_off[g], (size_t)n); o += n; }
+    }
+    out->str_off[ng] = o;
+    return FIG_OK;
+}
+
+extern "C" int fig_fill_gaps(fig_ctx *ctx, const fig_gap_batch *batch, fig_gap_results *out) {
+    int rc = fig_batch_upload(ctx, batch);
+    if (rc) return rc;
+    rc = fig_fill_resident(ctx, out);
+    fig_batch_free(ctx);
+    return rc;
+}
+
+extern "C" int fig_get_stats(const fig_ctx *ctx, fig_stats *out) {
+    if (!ctx || !out) return FIG_EINVAL;
+    *out = ctx->stats;
+    return FIG_OK;
+}

@@ -1,0 +1,446 @@
+// fig_engine.h -- the per-gap EM gap-filling engine for gfx950 (MI355X).
+//
+// One workgroup owns one gap at a time and runs the whole of what the reference does per gap
+// (GapFiller::fillGap, Figbird.cpp:6201-6570) without leaving the device: candidate-length
+// loop x EM loop x placeReads (E-step pile-up + MLE pass), consensus, the unmapped/partial
+// post-processing heuristics and finalize.  Workgroups pull gaps from a cost-sorted queue.
+//
+// Parallel structure inside a workgroup (nt = blockDim.x lanes, 64..1024):
+//   * E-step (A4): lanes = placements of the current read; each lane runs the ordered
+//     product chain over the read's bases; the per-placement weight goes to LDS (wbuf);
+//     then lanes = gap columns, each column adding the weights that cover it in exactly the
+//     (read, placement) order of the reference, so countsGap is bit-identical (no atomics).
+//   * MLE pass (A5/A12): lanes = placements, workgroup arg-max ("first maximum wins").
+//   * computeProbsGap / computeErrorProbsGap / computeSequence (A3/A6): lanes = gap columns.
+//   * control logic and the integer/string heuristics (A7-A11): lane 0, between barriers.
+// LDS holds the per-column probability tables P[4][G], Q[5][G] (72 B/column), the weight
+// buffer, the staged read and the consensus codes; flank columns are one-hot and are kept
+// as byte codes plus a 6x5 table.  Everything else is in a per-workgroup HBM/L2 scratch slab.
+//
+// The same source also compiles under FIG_EMU (tests/emu) as a ONE-LANE host emulation used
+// only by the CPU unit tests to check the control logic against the oracle; it is not a
+// fallback and is never linked into libfighip.so.
+#ifndef FIG_ENGINE_H
+#define FIG_ENGINE_H
+
+#include "fig_types.h"
+
+#ifdef FIG_EMU
+#include <cmath>
+#include <cstring>
+#define FIG_D static inline
+#define FIG_HD static inline
+#define FIG_SYNC() ((void)0)
+FIG_D double fig_log10(double x) { return log10(x); }
+FIG_D double fig_log(double x) { return log(x); }
+FIG_D double fig_exp(double x) { return exp(x); }
+FIG_D double fig_pow10(double x) { return pow(10, x); }
+FIG_D int fig_atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
+FIG_D void fig_atomic_max_i32(int *p, int v) { if (v > *p) *p = v; }
+FIG_D void fig_atomic_min_i32(int *p, int v) { if (v < *p) *p = v; }
+FIG_D void fig_atomic_or_i32(int *p, int v) { *p |= v; }
+FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
+#else
+#include <hip/hip_runtime.h>
+#define FIG_D __device__ static
+#define FIG_HD __host__ __device__ static
+#define FIG_SYNC() __syncthreads()
+FIG_D double fig_log10(double x) { return log10(x); }
+FIG_D double fig_log(double x) { return log(x); }
+FIG_D double fig_exp(double x) { return exp(x); }
+FIG_D double fig_pow10(double x) { return pow(10.0, x); }
+FIG_D int fig_atomic_add_i32(int *p, int v) { return atomicAdd(p, v); }
+FIG_D void fig_atomic_max_i32(int *p, int v) { atomicMax(p, v); }
+FIG_D void fig_atomic_min_i32(int *p, int v) { atomicMin(p, v); }
+FIG_D void fig_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
+FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+#endif
+
+#define FIG_NOPOS 0x7fffffff
+
+// ---------------------------------------------------------------------------------------
+// Workgroup-shared scalar state (LDS).  Names follow GapFiller's members (Figbird.cpp:1563-1635).
+struct FigState {
+    int G, ncols;                    // this->gapLength ; columns spanned at the last initialize_start_end
+    int left, right;                 // left_maxDistance, right_maxDistance (file-level globals in the reference)
+    int side_limit; long long end_pos_max;
+    int valid_count, invalid_count, partial_read_count;
+    double region_perct, region_perct_max;
+    int partial_read_len, rep_flag, one_side_repeat_flag, large_gap_flag, comp_count;
+    int left_max, right_min, discont_or_not;
+    int psr_temp[2], psr_final[2];
+    int umaxleftf, umaxrightf, ucoverf;
+    int num_itr, overlap_threshold, gaptofill;
+    int gl_len, gr_len, pl_len, pr_len;
+    int cons_len, best_len, cur_len, prev_len, orig_len;
+    unsigned char gap_left[32], gap_right[32];
+    unsigned char partial_left[100], partial_right[100];
+    double FP[6][5], FQ[6][5];       // flank-column tables by flank code (0..3 one-hot, 4 = N, 5 = outside window)
+    // reductions / broadcast
+    double red_v[16]; int red_i[16];
+    double bc_d; int bc_i, bc_j;
+    int ibuf[8];
+    double lik;                      // return value of placeReads / run
+    int ctl[8];
+};
+
+struct FigTrip { int v[3]; };
+
+// Per-workgroup scratch slab (HBM, L2-resident while the gap is being worked on).
+struct FigScr {
+    double *cnt;       // countsGap      [5][capG]   (gap columns only)
+    double *ncnt;      // new_counts_gap [5][capG]
+    double *tmp;       // qual_gap (partial) / count_pos (seed re-weighting) [5][capG]
+    int *pc;           // partial_count_array [4][capG]
+    int *cov;          // gap_coverage [capG]
+    int *region;       // [capG+8]
+    unsigned char *cons, *best, *cur, *prev, *orig;   // strings [capG+1]
+    unsigned char *colchar;                           // [capG] per-column majority code (update_partial_prob)
+    // per unmapped read
+    unsigned char *mark, *saved;
+    double *maxlv;
+    int *frp;          // final_readpos [R][2] (pos, len) ; id is the index
+    int *org;          // unmapped_read_pos_arr_org [R][2]
+    int *fin;          // finalize's unmapped_read_pos_arr [R][2]
+    FigTrip *sortbuf;  // [R]
+    // per partial read
+    int *repeatflag;   // [P][3]
+    int *ppos_org;     // partial_read_pos_arr_org [P][3]
+    int *pflag;        // [P][2]
+    int *prf;          // partial_read_flag [P][3]
+    int *lcross, *rcross; unsigned char *smflag;      // [P]
+    // per candidate
+    int *used_read_arr; int *lrmd;                    // [C], [C][2]
+    double *Pg, *Qg;   // global copies of P/Q when they do not fit in LDS
+    double *wg;        // global weight buffer when it does not fit in LDS
+};
+
+FIG_HD long long fig_align8(long long x) { return (x + 7) & ~7LL; }
+
+// Carve the slab.  Returns the total size when base == nullptr.
+FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int capP, int capC, int capW, FigScr *s) {
+    long long o = 0;
+#define FIG_CARVE(field, type, count) do { if (s) s->field = (type *)(base + o); o = fig_align8(o + (long long)sizeof(type) * (count)); } while (0)
+    FIG_CARVE(cnt, double, 5LL * capG);
+    FIG_CARVE(ncnt, double, 5LL * capG);
+    FIG_CARVE(tmp, double, 5LL * capG);
+    FIG_CARVE(Pg, double, 4LL * capG);
+    FIG_CARVE(Qg, double, 5LL * capG);
+    FIG_CARVE(wg, double, capW);
+    FIG_CARVE(maxlv, double, capR > capP ? capR : capP);
+    FIG_CARVE(pc, int, 4LL * capG);
+    FIG_CARVE(cov, int, capG);
+    FIG_CARVE(region, int, 2LL * capG + 16);
+    FIG_CARVE(frp, int, 2LL * capR);
+    FIG_CARVE(org, int, 2LL * capR);
+    FIG_CARVE(fin, int, 2LL * capR);
+    FIG_CARVE(sortbuf, FigTrip, capR);
+    FIG_CARVE(repeatflag, int, 3LL * capP);
+    FIG_CARVE(ppos_org, int, 3LL * capP);
+    FIG_CARVE(pflag, int, 2LL * capP);
+    FIG_CARVE(prf, int, 3LL * capP);
+    FIG_CARVE(lcross, int, capP);
+    FIG_CARVE(rcross, int, capP);
+    FIG_CARVE(used_read_arr, int, capC);
+    FIG_CARVE(lrmd, int, 2LL * capC);
+    FIG_CARVE(cons, unsigned char, capG + 8);
+    FIG_CARVE(best, unsigned char, capG + 8);
+    FIG_CARVE(cur, unsigned char, capG + 8);
+    FIG_CARVE(prev, unsigned char, capG + 8);
+    FIG_CARVE(orig, unsigned char, capG + 8);
+    FIG_CARVE(colchar, unsigned char, capG + 8);
+    FIG_CARVE(mark, unsigned char, capR + 8);
+    FIG_CARVE(saved, unsigned char, capR + 8);
+    FIG_CARVE(smflag, unsigned char, capP + 8);
+#undef FIG_CARVE
+    return o;
+}
+
+// Everything a lane needs; lives in registers / private memory.
+struct FigEng {
+    int tid, nt;
+    const FigDevModel *M;
+    const FigDevBatch *B;
+    const FigDevGap *g;
+    FigState *S;
+    FigScr scr;
+    double *P, *Q;                   // [4][capG], [5][capG]  (LDS or scratch)
+    double *wbuf;                    // [capW]
+    unsigned char *rb;               // staged read codes [FIG_MAX_READLEN + 8]
+    unsigned char *gs;               // consensus codes of the gap columns for the MLE pass [capG]
+    int capG, capW;
+    unsigned long long flops;        // per-lane algorithmic flop count
+};
+
+// ---------------------------------------------------------------------------------------
+// packed read access
+FIG_D int fig_read_code(const uint32_t *packed, long long woff, int len, int j) {
+    int nw2 = (len + 15) >> 4;
+    uint32_t w = packed[woff + (j >> 4)];
+    uint32_t m = packed[woff + nw2 + (j >> 5)];
+    int c = (w >> ((j & 15) * 2)) & 3;
+    return ((m >> (j & 31)) & 1) ? 4 : c;
+}
+
+FIG_D int fig_flank_l(const FigEng &E, int k) {      // base at gapStart-k, k >= 1
+    if (k > FIG_FLANK) return 4;
+    return E.B->flank[E.g->flankOff + (k - 1)];
+}
+FIG_D int fig_flank_r(const FigEng &E, int k) {      // base at gapStart+G0+k, k >= 0
+    if (k >= FIG_FLANK) return 4;
+    return E.B->flank[E.g->flankOff + FIG_FLANK + k];
+}
+
+// Stage read (unmapped u / partial p) into LDS as byte codes.  Caller syncs afterwards.
+FIG_D void fig_stage_read(FigEng &E, const FigDevReads &R, long long idx) {
+    int len = R.len[idx];
+    long long woff = R.woff[idx];
+    for (int j = E.tid; j < len; j += E.nt) E.rb[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j);
+}
+
+// Private-memory copy of a read (serial string heuristics).
+FIG_D int fig_load_read(const FigEng &E, const FigDevReads &R, long long idx, unsigned char *dst) {
+    int len = R.len[idx];
+    long long woff = R.woff[idx];
+    for (int j = 0; j < len; j++) dst[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j);
+    return len;
+}
+
+// ---------------------------------------------------------------------------------------
+// workgroup reductions
+struct FigBest { double v; int o; };
+
+// "first maximum wins": larger v, ties -> smaller o.  Entries with o == FIG_NOPOS are empty.
+FIG_D FigBest fig_best_merge(FigBest a, FigBest b) {
+    if (b.o == FIG_NOPOS) return a;
+    if (a.o == FIG_NOPOS) return b;
+    if (b.v > a.v || (b.v == a.v && b.o < a.o)) return b;
+    return a;
+}
+
+FIG_D FigBest fig_block_best(FigEng &E, FigBest x) {
+#ifdef FIG_EMU
+    return x;
+#else
+    for (int off = 32; off > 0; off >>= 1) {
+        FigBest y;
+        y.v = __shfl_down(x.v, off, 64);
+        y.o = __shfl_down(x.o, off, 64);
+        x = fig_best_merge(x, y);
+    }
+    int wave = E.tid >> 6, nw = (E.nt + 63) >> 6;
+    if (nw == 1) {
+        x.v = __shfl(x.v, 0, 64);
+        x.o = __shfl(x.o, 0, 64);
+        return x;
+    }
+    FIG_SYNC();                       // previous users of red_* are done
+    if ((E.tid & 63) == 0) { E.S->red_v[wave] = x.v; E.S->red_i[wave] = x.o; }
+    FIG_SYNC();
+    FigBest r; r.v = E.S->red_v[0]; r.o = E.S->red_i[0];
+    for (int w = 1; w < nw; w++) { FigBest y; y.v = E.S->red_v[w]; y.o = E.S->red_i[w]; r = fig_best_merge(r, y); }
+    return r;
+#endif
+}
+
+// ---------------------------------------------------------------------------------------
+// initialize_start_end, Figbird.cpp:2269-2296 (lane 0)
+FIG_D void fig_ise(FigEng &E) {
+    FigState &S = *E.S;
+    long long gs = E.g->gapStart, cl = E.g->contigLen;
+    if (gs - S.left < 0) { S.left = (int)gs; if (S.side_limit > S.left) S.side_limit = S.left; }
+    if (gs + S.G + S.right > cl) { S.right = (int)(cl - (gs + S.G)); if (S.side_limit > S.right) S.side_limit = S.right; }
+    long long endPos = gs + S.G + S.right;
+    if (endPos > S.end_pos_max) S.end_pos_max = endPos;
+    S.ncols = S.G;
+}
+
+// Flank-column probability rows (computeProbsGap + computeErrorProbsGap on a one-hot /
+// N column, Figbird.cpp:2094-2109, 2122-2136).  Lane 0, once per gap.
+FIG_D void fig_flank_tables(FigEng &E) {
+    FigState &S = *E.S;
+    for (int c = 0; c < 6; c++) {
+        double cnt[5] = {0, 0, 0, 0, 0};
+        if (c < 5) cnt[c] = 1;
+        double total = 0;
+        for (int j = 0; j < 5; j++) total = total + cnt[j];
+        double Ncount = cnt[4];
+        double pr[5];
+        for (int j = 0; j < 4; j++) pr[j] = (c < 5) ? ((cnt[j] + (Ncount / 4)) / total) : 0.0;
+        pr[4] = 0;
+        for (int j = 0; j < 5; j++) {
+            double sum = 0;
+            for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * E.M->T[k * 5 + j]; }
+            S.FQ[c][j] = (c < 5) ? sum : 0.0;
+            S.FP[c][j] = pr[j];
+        }
+    }
+}
+
+// Code of window column x (gap-relative) for the E-step: -1 = left of the window (skipped,
+// `index<0`, Figbird.cpp:3578), 0..4 flank base, 5 = right of the window (all-zero row), 6 = gap column.
+FIG_D int fig_col_kind(const FigEng &E, int x, int G, int left, int right) {
+    if (x < 0) { if (x < -left) return -1; return fig_flank_l(E, -x); }
+    if (x < G) return 6;
+    if (x < G + right) return fig_flank_r(E, x - G);
+    return 5;
+}
+// charCode of gapString[index] for the MLE pass (Figbird.cpp:3765); outside the string -> 4.
+FIG_D int fig_from_code(const FigEng &E, int x, int G, int left, int right) {
+    if (x < 0) { if (x < -left) return 4; return fig_flank_l(E, -x); }
+    if (x < G) return E.gs[x];
+    if (x < G + right) return fig_flank_r(E, x - G);
+    return 4;
+}
+
+// ---------------------------------------------------------------------------------------
+// computeProbsGap(0) + computeErrorProbsGap on the gap columns (A3). All lanes; caller syncs.
+FIG_D void fig_compute_probs(FigEng &E) {
+    int n = E.S->ncols, cg = E.capG;
+    const double *T = E.M->T;
+    for (int x = E.tid; x < n; x += E.nt) {
+        double c0 = E.scr.cnt[x], c1 = E.scr.cnt[cg + x], c2 = E.scr.cnt[2 * cg + x], c3 = E.scr.cnt[3 * cg + x], c4 = E.scr.cnt[4 * cg + x];
+        double total = 0;
+        total = total + c0; total = total + c1; total = total + c2; total = total + c3; total = total + c4;
+        double pr[4];
+        if (total) {
+            double nq = c4 / 4;
+            pr[0] = (c0 + nq) / total; pr[1] = (c1 + nq) / total; pr[2] = (c2 + nq) / total; pr[3] = (c3 + nq) / total;
+        } else { pr[0] = pr[1] = pr[2] = pr[3] = .25; }
+        for (int j = 0; j < 4; j++) E.P[j * cg + x] = pr[j];
+        for (int j = 0; j < 5; j++) {
+            double sum = 0;
+            for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
+            E.Q[j * cg + x] = sum;
+        }
+    }
+}
+FIG_D void fig_compute_errprobs_only(FigEng &E) {
+    int n = E.S->ncols, cg = E.capG;
+    const double *T = E.M->T;
+    for (int x = E.tid; x < n; x += E.nt) {
+        double pr[4];
+        for (int j = 0; j < 4; j++) pr[j] = E.P[j * cg + x];
+        for (int j = 0; j < 5; j++) {
+            double sum = 0;
+            for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
+            E.Q[j * cg + x] = sum;
+        }
+    }
+}
+
+// computeSequence, Figbird.cpp:4417-4508.  All lanes; ends with a barrier.
+FIG_D void fig_compute_sequence(FigEng &E, int check, int choice) {
+    int n = E.S->ncols, cg = E.capG;
+    const double *A = choice == 0 ? E.scr.cnt : E.scr.ncnt;
+    for (int x = E.tid; x < n; x += E.nt) {
+        double mx = 0; int mi = -1;
+        for (int j = 0; j <= 4; j++) { double v = A[j * cg + x]; if (v > mx) { mx = v; mi = j; } }
+        int coverage_flag = 1;
+        if (check == 1) { int cv = (int)mx; E.scr.cov[x] = cv; if (cv <= 0) coverage_flag = 0; }
+        unsigned char c = 4;
+        if (((mi != -1) || (!check)) && coverage_flag) c = (mi >= 0 && mi <= 3) ? (unsigned char)mi : 4;
+        E.scr.cons[x] = c;
+    }
+    if (E.tid == 0) E.S->cons_len = n < 0 ? 0 : n;
+    FIG_SYNC();
+}
+
+FIG_D void fig_copy_str(FigEng &E, unsigned char *dst, int *dlen, const unsigned char *src, int slen) {
+    for (int x = E.tid; x < slen; x += E.nt) dst[x] = src[x];
+    if (E.tid == 0) *dlen = slen;
+    FIG_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------
+// libstdc++ std::sort replica (introsort, threshold 16) on triples keyed by v[0], so that reads
+// with equal positions end up in exactly the order the reference binary leaves them in
+// (findOverlapUnmapped / findDiscontinous, Figbird.cpp:2956, 4635).  Serial (lane 0).
+FIG_D bool fig_tlt(const FigTrip &a, const FigTrip &b) { return a.v[0] < b.v[0]; }
+FIG_D void fig_tswap(FigTrip &a, FigTrip &b) { FigTrip t = a; a = b; b = t; }
+
+FIG_D void fig_adjust_heap(FigTrip *first, int holeIndex, int len, FigTrip value) {
+    int topIndex = holeIndex, secondChild = holeIndex;
+    while (secondChild < (len - 1) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        if (fig_tlt(first[secondChild], first[secondChild - 1])) secondChild--;
+        first[holeIndex] = first[secondChild];
+        holeIndex = secondChild;
+    }
+    if ((len & 1) == 0 && secondChild == (len - 2) / 2) {
+        secondChild = 2 * (secondChild + 1);
+        first[holeIndex] = first[secondChild - 1];
+        holeIndex = secondChild - 1;
+    }
+    int parent = (holeIndex - 1) / 2;
+    while (holeIndex > topIndex && fig_tlt(first[parent], value)) {
+        first[holeIndex] = first[parent];
+        holeIndex = parent;
+        parent = (holeIndex - 1) / 2;
+    }
+    first[holeIndex] = value;
+}
+FIG_D void fig_heapsort(FigTrip *first, int n) {         // __partial_sort(first,last,last): make_heap + sort_heap
+    if (n < 2) return;
+    for (int parent = (n - 2) / 2;; parent--) { FigTrip v = first[parent]; fig_adjust_heap(first, parent, n, v); if (parent == 0) break; }
+    for (int last = n; last > 1; last--) { FigTrip v = first[last - 1]; first[last - 1] = first[0]; fig_adjust_heap(first, 0, last - 1, v); }
+}
+FIG_D void fig_unguarded_linear_insert(FigTrip *a, int last) {
+    FigTrip val = a[last];
+    int next = last - 1;
+    while (fig_tlt(val, a[next])) { a[last] = a[next]; last = next; next--; }
+    a[last] = val;
+}
+FIG_D void fig_insertion_sort(FigTrip *a, int first, int last) {
+    if (first == last) return;
+    for (int i = first + 1; i != last; ++i) {
+        if (fig_tlt(a[i], a[first])) { FigTrip val = a[i]; for (int k = i; k > first; k--) a[k] = a[k - 1]; a[first] = val; }
+        else fig_unguarded_linear_insert(a, i);
+    }
+}
+FIG_D void fig_std_sort(FigTrip *a, int n) {
+    if (n <= 0) return;
+    int lg = 0; { int t = n; while (t > 1) { t >>= 1; lg++; } }
+    int stack_f[64], stack_l[64], stack_d[64], sp = 0;
+    stack_f[0] = 0; stack_l[0] = n; stack_d[0] = lg * 2; sp = 1;
+    while (sp > 0) {
+        sp--;
+        int first = stack_f[sp], last = stack_l[sp], depth = stack_d[sp];
+        while (last - first > 16) {
+            if (depth == 0) { fig_heapsort(a + first, last - first); break; }
+            --depth;
+            int mid = first + (last - first) / 2;
+            {   // __move_median_to_first(first, first+1, mid, last-1)
+                int A = first + 1, Bm = mid, C = last - 1;
+                if (fig_tlt(a[A], a[Bm])) {
+                    if (fig_tlt(a[Bm], a[C])) fig_tswap(a[first], a[Bm]);
+                    else if (fig_tlt(a[A], a[C])) fig_tswap(a[first], a[C]);
+                    else fig_tswap(a[first], a[A]);
+                } else if (fig_tlt(a[A], a[C])) fig_tswap(a[first], a[A]);
+                else if (fig_tlt(a[Bm], a[C])) fig_tswap(a[first], a[C]);
+                else fig_tswap(a[first], a[Bm]);
+            }
+            int lo = first + 1, hi = last;
+            while (true) {
+                while (fig_tlt(a[lo], a[first])) ++lo;
+                --hi;
+                while (fig_tlt(a[first], a[hi])) --hi;
+                if (!(lo < hi)) break;
+                fig_tswap(a[lo], a[hi]);
+                ++lo;
+            }
+            int cut = lo;
+            // recurse on [cut,last) first (as the reference does), then loop on [first,cut)
+            if (sp < 63) { stack_f[sp] = first; stack_l[sp] = cut; stack_d[sp] = depth; sp++; }
+            first = cut;
+            // NB: libstdc++ recurses into the right part and iterates on the left; the two
+            // sub-ranges are disjoint, so processing order does not change the result.
+        }
+    }
+    if (n > 16) { fig_insertion_sort(a, 0, 16); for (int i = 16; i != n; ++i) fig_unguarded_linear_insert(a, i); }
+    else fig_insertion_sort(a, 0, n);
+}
+
+#include "fig_engine_core.h"
+
+#endif

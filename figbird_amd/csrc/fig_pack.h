@@ -1,0 +1,188 @@
+// fig_pack.h -- host-side packer: fig_gap_batch (caller arrays) -> device-layout arrays.
+// Pure C++ (no HIP) so that the CPU unit-test emulation (tests/emu) packs exactly like
+// libfighip.so does.  Role in the reference: the per-gap preamble of Figbird.cpp's main loop
+// (findFrac/alloc_arg :6879-6906,:7393-7400; read caps :5763,:1814; flank window :2342-2372).
+#ifndef FIG_PACK_H
+#define FIG_PACK_H
+#include <algorithm>
+#include <cstring>
+#include <vector>
+#include "../../include/figbird_hip.h"
+#include "fig_types.h"
+
+// findFrac + alloc_arg, Figbird.cpp:6879-6906, :7393-7400 (float arithmetic as in the reference)
+static void gap_alloc(const fig_model *m, int G0, int *alloc_arg, float *f1, float *f2, int *lgf) {
+    int factor = 3 * m->partial_len;
+    int mid_limitp = 2 * m->partial_len, mid_limitu = m->unm_limit;
+    float info[3] = {0, 0, 0};
+    int ret;
+    if (m->partial_flag) {
+        if (G0 <= mid_limitp / 2) { info[0] = .00001; info[1] = (float)factor / G0; ret = -1; }
+        else if (G0 <= mid_limitp) { info[0] = .00001; info[1] = 5.0; ret = 5; }
+        else { info[0] = 1; info[1] = 1; ret = 3; }
+    } else {
+        if (G0 <= mid_limitu / 3) { info[0] = .3; info[1] = (float)factor / G0; ret = -1; }
+        else if (G0 <= mid_limitu) { info[0] = .5; info[1] = 2.5; ret = 3; }
+        else { info[0] = 1; info[1] = 1; info[2] = 1; ret = 1; }
+    }
+    *alloc_arg = (ret == -1) ? factor * 3 : G0 * ret;
+    *f1 = info[0]; *f2 = info[1]; *lgf = (int)info[2];
+}
+
+static int gap_range(int G0, float f1, float f2) {
+    int gapMin = (int)(G0 * f1), gapMax = (int)(G0 * f2);
+    int r = gapMax - gapMin + 1;
+    return r < 1 ? 1 : r;
+}
+
+static inline int code_of(char c) {
+    switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
+}
+
+static void pack_read(const char *s, int len, std::vector<uint32_t> &out) {
+    int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5;
+    size_t base = out.size();
+    out.resize(base + nw2 + nwm, 0u);
+    for (int j = 0; j < len; j++) {
+        int c = code_of(s[j]);
+        if (c < 4) out[base + (j >> 4)] |= (uint32_t)c << ((j & 15) * 2);
+        else out[base + nw2 + (j >> 5)] |= 1u << (j & 31);
+    }
+}
+
+
+struct FigLaunchClass { int capG, capW, nt; bool pq_lds, w_lds; size_t lds; int q_begin, q_end; };
+
+struct FigPacked {
+    std::vector<FigDevGap> gaps;
+    std::vector<int32_t> order;
+    std::vector<uint8_t> flank, qual;
+    std::vector<uint32_t> packed;
+    std::vector<int32_t> u_pos, u_aux, u_len, p_pos, p_aux, p_clip, p_ref, p_len;
+    std::vector<int64_t> u_woff, p_woff, p_qoff, str_off;
+    std::vector<FigLaunchClass> classes;
+    int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0;
+    int64_t str_total = 0, n_gaps = 0;
+    int64_t packed_bytes() const {
+        return (int64_t)(packed.size() * 4 + flank.size() + gaps.size() * sizeof(FigDevGap) + qual.size() +
+                         (u_pos.size() * 3 + p_pos.size() * 5) * 4 + (u_woff.size() + p_woff.size() + p_qoff.size()) * 8);
+    }
+};
+
+// lds_fixed = bytes of LDS the kernel needs besides P/Q and the weight buffer, as a function of capG.
+static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_bytes, FigPacked &K) {
+    int64_t ng = b->n_gaps;
+    if (ng < 0) return FIG_EINVAL;
+    if (ng > 0 && (!b->gap_contig || !b->gap_start || !b->gap_len || !b->contig_off || !b->contig_seq || !b->p_read_off)) return FIG_EINVAL;
+    if (m->unmapped_flag && ng > 0 && !b->u_read_off) return FIG_EINVAL;
+    if (m->max_distance < m->max_read_length) return FIG_EUNSUP;       // placements must stay inside the +-D window
+    K.n_gaps = ng;
+    K.gaps.assign(ng, FigDevGap());
+    K.flank.assign((size_t)ng * 2 * FIG_FLANK, 4);
+    K.str_off.assign(ng + 1, 0);
+    std::vector<double> cost(ng, 0.0);
+    int64_t str_total = 0;
+    for (int64_t g = 0; g < ng; g++) {
+        FigDevGap &d = K.gaps[g];
+        int ci = b->gap_contig[g];
+        if (ci < 0 || ci >= b->n_contigs) return FIG_EINVAL;
+        int64_t c0 = b->contig_off[ci], c1 = b->contig_off[ci + 1];
+        d.contigLen = c1 - c0; d.gapStart = b->gap_start[g]; d.G0 = b->gap_len[g];
+        if (d.G0 < 1 || d.gapStart < 0 || d.gapStart + d.G0 > d.contigLen) return FIG_EINVAL;
+        d.stat2 = b->gap_stat2 ? b->gap_stat2[g * 3 + 1] : 0;
+        d.stat3 = b->gap_stat2 ? b->gap_stat2[g * 3 + 2] : 0;
+        d.fillflag = b->gap_fillflag ? b->gap_fillflag[g] : 1;
+        gap_alloc(m, d.G0, &d.alloc_arg, &d.gpf1, &d.gpf2, &d.lgf);
+        if (d.alloc_arg < d.G0) d.alloc_arg = d.G0;
+        d.gapNo = (int32_t)g;
+        d.flankOff = g * 2 * FIG_FLANK;
+        uint8_t *fl = &K.flank[(size_t)d.flankOff];
+        const char *cs = b->contig_seq + c0;
+        for (int k = 1; k <= FIG_FLANK; k++) { int64_t a = d.gapStart - k; fl[k - 1] = a >= 0 ? (uint8_t)code_of(cs[a]) : 4; }
+        for (int k = 0; k < FIG_FLANK; k++) { int64_t a = d.gapStart + d.G0 + k; fl[FIG_FLANK + k] = a < d.contigLen ? (uint8_t)code_of(cs[a]) : 4; }
+        d.strOff = str_total; K.str_off[g] = str_total; str_total += d.alloc_arg + 1;
+        d.uBase = (int64_t)K.u_pos.size(); d.nU = 0;
+        if (m->unmapped_flag) {
+            int64_t r0 = b->u_read_off[g], r1 = b->u_read_off[g + 1];
+            int64_t n = r1 - r0;
+            if (n > FIG_READ_CAP) n = FIG_READ_CAP;                      // parseUnmapped stops at unmapped_limit (:5763)
+            for (int64_t r = r0; r < r0 + n; r++) {
+                int len = (int)(b->u_seq_off[r + 1] - b->u_seq_off[r]);
+                if (len > FIG_MAX_READLEN || len > m->max_read_length || len < 1) return FIG_EUNSUP;
+                K.u_pos.push_back(b->u_anchor_pos[r]); K.u_aux.push_back(b->u_is_reverse[r] ? 1 : 0); K.u_len.push_back(len);
+                K.u_woff.push_back((int64_t)K.packed.size());
+                pack_read(b->u_seq + b->u_seq_off[r], len, K.packed);
+            }
+            d.nU = (int32_t)n;
+        }
+        d.pBase = (int64_t)K.p_pos.size(); d.nP = 0;
+        {
+            int64_t r0 = b->p_read_off[g], r1 = b->p_read_off[g + 1];
+            int64_t n = r1 - r0;
+            if (n > FIG_READ_CAP + 1) n = FIG_READ_CAP + 1;              // every per-file loop stops after 3001 lines
+            for (int64_t r = r0; r < r0 + n; r++) {
+                int len = (int)(b->p_seq_off[r + 1] - b->p_seq_off[r]);
+                if (len > FIG_MAX_READLEN || len < 1) return FIG_EUNSUP;
+                K.p_pos.push_back(b->p_pos[r]); K.p_aux.push_back(b->p_match[r]); K.p_clip.push_back(b->p_clipped_index[r]);
+                K.p_ref.push_back(b->p_ref_pos[r]); K.p_len.push_back(len);
+                K.p_woff.push_back((int64_t)K.packed.size());
+                pack_read(b->p_seq + b->p_seq_off[r], len, K.packed);
+                K.p_qoff.push_back((int64_t)K.qual.size());
+                if (b->p_qual) K.qual.insert(K.qual.end(), b->p_qual + b->p_seq_off[r], b->p_qual + b->p_seq_off[r] + len);
+                else K.qual.insert(K.qual.end(), (size_t)len, (uint8_t)'I');
+            }
+            d.nP = (int32_t)n;
+        }
+        K.capR = std::max(K.capR, d.nU); K.capP = std::max(K.capP, d.nP);
+        int range = gap_range(d.G0, d.gpf1, d.gpf2);
+        K.capC = std::max(K.capC, range);
+        K.capG = std::max(K.capG, d.alloc_arg);
+        double L = m->max_read_length;
+        if (m->unmapped_flag) cost[g] = (double)d.nU * std::min<double>(d.alloc_arg + L, 2200.0) * L * (d.lgf ? 6.0 : range * 14.0);
+        else cost[g] = (double)d.nP * L * L * range * 3.0;
+        if (d.fillflag == -1) cost[g] = 1;
+    }
+    K.str_total = str_total; K.str_off[ng] = str_total;
+    K.capG = (K.capG + 7) & ~7;
+    K.capW = K.capG + FIG_MAX_READLEN + 8;
+    // ---- LDS classes by column capacity; within a class, most expensive gaps first
+    struct ClsDef { int capG, nt; };
+    const ClsDef defs[] = {{384, 256}, {1024, 512}, {1856, 1024}, {1 << 30, 1024}};
+    K.order.clear(); K.classes.clear();
+    int prevcap = 0;
+    for (const ClsDef &cd : defs) {
+        std::vector<int32_t> ids;
+        int mx = 8;
+        for (int64_t g = 0; g < ng; g++)
+            if (K.gaps[g].alloc_arg > prevcap && K.gaps[g].alloc_arg <= cd.capG) { ids.push_back((int32_t)g); mx = std::max(mx, K.gaps[g].alloc_arg); }
+        prevcap = cd.capG;
+        if (ids.empty()) continue;
+        std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t c) { return cost[a] > cost[c]; });
+        FigLaunchClass c;
+        c.capG = (mx + 7) & ~7;
+        c.capW = c.capG + FIG_MAX_READLEN + 8;
+        c.nt = cd.nt;
+        size_t fixed = state_bytes + (size_t)((c.capG + 7) & ~7) + FIG_MAX_READLEN + 16;
+        size_t pq = (size_t)9 * c.capG * sizeof(double), wb = (size_t)c.capW * sizeof(double);
+        const size_t LDS_MAX = 160 * 1024 - 512;
+        c.pq_lds = fixed + pq <= LDS_MAX;
+        c.w_lds = fixed + (c.pq_lds ? pq : 0) + wb <= LDS_MAX;
+        c.lds = fixed + (c.pq_lds ? pq : 0) + (c.w_lds ? wb : 0);
+        c.q_begin = (int)K.order.size();
+        for (int32_t id : ids) { K.gaps[id].cls = (int)K.classes.size(); K.order.push_back(id); }
+        c.q_end = (int)K.order.size();
+        K.classes.push_back(c);
+    }
+    return FIG_OK;
+}
+
+static int64_t fig_pack_results_capacity(const fig_model *m, const fig_gap_batch *b) {
+    int64_t tot = 0;
+    for (int64_t g = 0; g < b->n_gaps; g++) {
+        int a, lgf; float f1, f2;
+        gap_alloc(m, b->gap_len[g], &a, &f1, &f2, &lgf);
+        tot += std::max(a, b->gap_len[g]) + 1;
+    }
+    return tot;
+}
+#endif

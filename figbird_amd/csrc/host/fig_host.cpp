@@ -1,0 +1,587 @@
+// fig_host.cpp -- see fig_host.h.  Reference citations are to /root/reference (Figbird.cpp,
+// FillGaps.cpp, Preprocess.cpp); behaviour (including quirks) is kept.
+#include "fig_host.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+namespace fighost {
+
+static const int kMaxRec = 1024;            // MAX_REC_LEN: every reader uses fgets(line, 1024)
+static const int kReadCap = 3000;           // partial_limit / unmapped_limit
+
+// ------------------------------------------------------------------ scaffold
+bool load_scaffold(const std::string &path, Scaffold &sc, std::string &err) {
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) { err = "Can't open contig file"; return false; }
+    sc.names.clear(); sc.off.clear(); sc.seq.clear();
+    sc.off.push_back(0);
+    char *line = nullptr; size_t cap = 0; ssize_t n;
+    int64_t curlen = 0;
+    while ((n = getline(&line, &cap, f)) != -1) {
+        if (line[0] == ';') continue;
+        if (line[0] == '>') {
+            // name = first whitespace-delimited token of the header (Figbird.cpp:6994-6997)
+            std::string h(line + 1, (size_t)n - 1);
+            if (!h.empty()) h.pop_back();
+            size_t b = h.find_first_not_of(" \t\n");
+            std::string tok;
+            if (b != std::string::npos) { size_t e = h.find_first_of(" \t\n", b); tok = h.substr(b, e == std::string::npos ? std::string::npos : e - b); }
+            sc.names.push_back(tok);
+            if (curlen > 0) { sc.off.push_back((int64_t)sc.seq.size()); curlen = 0; }
+        } else {
+            // every sequence line loses its last character ('\n', or a base if the file does not end in one; :7030,7037)
+            size_t len = (size_t)n;
+            if (len > 0) len--;
+            for (size_t i = 0; i < len; i++) sc.seq.push_back((char)toupper((unsigned char)line[i]));
+            curlen += (int64_t)len;
+        }
+    }
+    free(line);
+    fclose(f);
+    sc.off.push_back((int64_t)sc.seq.size());
+    // a header with no sequence before the next header does not open a new contig in the reference; keep names aligned
+    while ((int64_t)sc.names.size() < (int64_t)sc.off.size() - 1) sc.names.push_back("");
+    return true;
+}
+
+// ------------------------------------------------------------------ model (A0)
+namespace {
+
+struct SamCols { char *qname, *cigar, *seq, *rname; int flag, pos, tlen; char md[1000]; int nh; bool ok; };
+
+// token order of processMapping / computeLikelihood (Figbird.cpp:864-901, :1198-1227)
+void split_sam(char *line, SamCols &c) {
+    c.ok = false; c.md[0] = 0; c.nh = 0;
+    char *sv = nullptr, *t;
+    if (!(c.qname = strtok_r(line, "\t", &sv))) return;
+    if (!(t = strtok_r(nullptr, "\t", &sv))) return; c.flag = atoi(t);
+    if (!(c.rname = strtok_r(nullptr, "\t", &sv))) return;
+    if (!(t = strtok_r(nullptr, "\t", &sv))) return; c.pos = atoi(t);
+    if (!(c.cigar = strtok_r(nullptr, "\t", &sv))) return;
+    if (!(t = strtok_r(nullptr, "\t", &sv))) return; c.tlen = atoi(t);
+    if (!(c.seq = strtok_r(nullptr, "\t", &sv))) return;
+    while ((t = strtok_r(nullptr, "\t\n", &sv)) != nullptr) {
+        if (t[0] == 'M' && t[1] == 'D') { strncpy(c.md, t, sizeof(c.md) - 1); c.md[sizeof(c.md) - 1] = 0; }
+        else if (t[0] == 'I' && t[1] == 'H') c.nh = atoi(t + 5);
+    }
+    c.ok = true;
+}
+
+inline int b5(char ch) { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 4; }
+
+struct Counts {
+    int L = 0; int maxInsertSize = 0, MAX_INSERT_SIZE = 0;
+    std::vector<long> insertCounts, errorPos, inPos, inLengths, delPos, delLengths, readLengths;
+    long errorTypes[5][5]; long baseCounts[5];
+    long discardedReads = 0, uniqueMappedReads = 0;
+};
+
+// walks a CIGAR the way the reference does (numbers split on "IDMS^", operator looked up by offset)
+template <class F> void walk_cigar(const char *cigar, const char *delims, F f) {
+    std::vector<char> tc(cigar, cigar + strlen(cigar) + 1);
+    int totalLength = 0;
+    for (char *t = strtok(tc.data(), delims); t; t = strtok(nullptr, delims)) {
+        unsigned long n = (unsigned long)atoi(t);
+        totalLength += (int)strlen(t);
+        f(cigar[totalLength], n);
+        totalLength++;
+    }
+}
+
+// walks the mismatches of an MD tag (Figbird.cpp:378-484): calls f(index_in_read_1based_after_inserts..)
+template <class F> void walk_md(const char *md, const std::vector<int> &inserts, const char *read, F f) {
+    unsigned long mdLength = strlen(md) - 5;
+    std::vector<char> tm(md, md + strlen(md) + 1);
+    strtok(tm.data(), ":");
+    strtok(nullptr, ":");
+    int index = 0, totalLength = 0;
+    char *temp;
+    while ((temp = strtok(nullptr, "ACGTN^\t\n ")) != nullptr) {
+        totalLength += (int)strlen(temp);
+        if ((unsigned long)totalLength < mdLength) {
+            char from = md[5 + totalLength];
+            if (from == '^') {
+                totalLength++;
+                index += atoi(temp);
+                for (unsigned long i = totalLength; i < mdLength; i++) {
+                    from = md[5 + totalLength];
+                    if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') totalLength++; else break;
+                }
+            } else if (from == 'A' || from == 'C' || from == 'G' || from == 'T' || from == 'N') {
+                totalLength++;
+                index += atoi(temp) + 1;
+                int curIndex = 0;
+                for (int i = 0; i < index; i++) curIndex += inserts[i];
+                f(index, curIndex, from, read[index - 1 + curIndex]);
+            } else break;
+        }
+    }
+}
+
+void update_insert_counts(Counts &c, int index) {       // Figbird.cpp:186-225
+    if (index <= 0) return;
+    if (index < c.maxInsertSize) { c.insertCounts[index]++; return; }
+    if (index > c.MAX_INSERT_SIZE) { c.discardedReads++; return; }
+    int t = std::max(c.maxInsertSize * 2, index);
+    c.insertCounts.resize((size_t)t + 1, 1);
+    c.insertCounts[index]++;
+    c.maxInsertSize = t;
+}
+
+void count_errors(Counts &c, const SamCols &s, const std::string &noErrorCigar) {   // processErrorTypes, :291-487
+    int strandNo = (s.flag & 16) >> 4;
+    const char *read = s.seq;
+    int readLength = 0;
+    for (; read[readLength]; readLength++) c.baseCounts[b5(read[readLength])]++;
+    c.readLengths[readLength - 1]++;
+    if (strcmp(s.md, noErrorCigar.c_str()) == 0) return;    // compares MD with "<L>M": never equal (quirk 5)
+    std::vector<int> inserts(readLength, 0);
+    int index = 0, curIndex = 0;
+    walk_cigar(s.cigar, "IDMS^\t\n ", [&](char op, unsigned long n) {
+        if (op == 'M') { index += (int)n; curIndex += (int)n; }
+        else if (op == 'I' || op == 'S') {
+            if (strandNo == 0) c.inPos[index]++; else c.inPos[readLength - index - 1]++;
+            c.inLengths[n - 1]++;
+            inserts[curIndex] = (int)n;
+            index += (int)n;
+        } else if (op == 'D') {
+            if (strandNo == 0) c.delPos[index]++; else c.delPos[readLength - index - 1]++;
+            c.delLengths[n - 1]++;
+        }
+    });
+    walk_md(s.md, inserts, read, [&](int idx, int cur, char from, char to) {
+        if (strandNo == 0) c.errorPos[idx - 1 + cur]++; else c.errorPos[readLength - idx - cur]++;
+        int f = b5(from), t = b5(to);
+        if (f != t) c.errorTypes[f][t]++;
+    });
+}
+
+struct Probs {
+    std::vector<double> errorPosDist, inPosDist, inLengthDist, delPosDist, delLengthDist, insertLengthDist, smoothed, noErrorProbs;
+    double errorTypeProbs[5][5], baseErrorRates[5];
+    double mean = 0, leftSD = 0, rightSD = 0;
+};
+
+void compute_probabilities(Counts &c, Probs &p) {        // computeProbabilites, :497-844
+    for (int i = 0; i < 5; i++) {
+        int errorCount = 0;
+        for (int j = 0; j < 5; j++) errorCount += (int)c.errorTypes[i][j];
+        for (int j = 0; j < 5; j++) p.errorTypeProbs[i][j] = (double)c.errorTypes[i][j] / errorCount;
+        p.baseErrorRates[i] = errorCount / (double)c.baseCounts[i];
+    }
+    double sum = 0;
+    for (int i = 0; i < 4; i++) sum += p.baseErrorRates[i];
+    for (int i = 0; i < 4; i++) p.baseErrorRates[i] = 4 * p.baseErrorRates[i] / sum;
+    p.baseErrorRates[4] = 1;
+    int L = c.L;
+    for (int i = L - 1; i > 0; i--) c.readLengths[i - 1] = c.readLengths[i] + c.readLengths[i - 1];
+    p.errorPosDist.resize(L); p.inPosDist.resize(L); p.inLengthDist.resize(L); p.delPosDist.resize(L); p.delLengthDist.resize(L);
+    for (int i = 0; i < L; i++) {
+        p.errorPosDist[i] = (double)c.errorPos[i] / c.readLengths[i];
+        p.inPosDist[i] = (double)c.inPos[i] / c.readLengths[i];
+        p.delPosDist[i] = (double)c.delPos[i] / c.readLengths[i];
+    }
+    int inCount = 0, delCount = 0;
+    for (int i = 0; i < L; i++) { inCount += (int)c.inLengths[i]; delCount += (int)c.delLengths[i]; }
+    for (int i = 0; i < L; i++) { p.inLengthDist[i] = (double)c.inLengths[i] / inCount; p.delLengthDist[i] = (double)c.delLengths[i] / delCount; }
+    int mis = c.maxInsertSize;
+    p.insertLengthDist.resize(mis);
+    long insCount = c.discardedReads;
+    sum = 0;
+    for (int i = 0; i < mis; i++) { insCount += (c.insertCounts[i] - 1); sum += i * (c.insertCounts[i] - 1); }
+    p.mean = sum / insCount;
+    for (int i = 0; i < mis; i++) p.insertLengthDist[i] = (double)c.insertCounts[i] / insCount;
+    p.noErrorProbs.resize(L);
+    double noErrorProb = 1.0;
+    for (int i = 0; i < L; i++) { noErrorProb *= (1 - p.errorPosDist[i] - p.inPosDist[i] - p.delPosDist[i]); p.noErrorProbs[i] = noErrorProb; }
+    // moving-average smoothing, window 12, edges copied, then the odd final correction (:646-677)
+    const int W = 12;
+    p.smoothed.resize(mis);
+    double windowSum = 0;
+    for (int i = 0; i < W; i++) p.smoothed[i] = p.insertLengthDist[i];
+    for (int i = 0; i < 2 * W + 1; i++) windowSum += p.insertLengthDist[i];
+    p.smoothed[W] = windowSum / (2 * W + 1);
+    for (int i = W + 1; i < mis - W; i++) {
+        windowSum -= p.insertLengthDist[i - W - 1];
+        windowSum += p.insertLengthDist[i + W];
+        p.smoothed[i] = windowSum / (2 * W + 1);
+    }
+    for (int i = mis - W; i < mis; i++) p.smoothed[i] = p.insertLengthDist[i];
+    for (int i = 0; i < mis; i++) p.smoothed[i] = p.smoothed[i] - 1 / (double)(insCount) + (1 / (double)mis) / (double)(insCount + 1);
+    // right / left SD about the mean (:785-802)
+    double insertSum = 0, insertCount = 0;
+    for (int i = (int)(p.mean + 1); i < mis; i++) {
+        insertSum = insertSum + (c.insertCounts[i] - 1) * (i - p.mean) * (i - p.mean);
+        insertCount += (c.insertCounts[i] - 1);
+    }
+    p.rightSD = sqrt(insertSum / insertCount);
+    insertSum = 0; insertCount = 0;
+    for (int i = std::max((int)(p.mean - 10 * p.rightSD), 0); i < p.mean; i++) {
+        insertSum = insertSum + (c.insertCounts[i] - 1) * (p.mean - i) * (p.mean - i);
+        insertCount += (c.insertCounts[i] - 1);
+    }
+    p.leftSD = sqrt(insertSum / insertCount);
+}
+
+long double error_prob(const Probs &p, const SamCols &s) {      // computeErrorProb, :952-1153 (long double)
+    int strandNo = (s.flag & 16) >> 4;
+    const char *read = s.seq;
+    unsigned long readLength = strlen(read);
+    long double errorProb = p.noErrorProbs[readLength - 1];
+    if (s.md[5] == '^') return errorProb;
+    std::vector<int> inserts(readLength, 0);
+    int index = 0, curIndex = 0;
+    walk_cigar(s.cigar, "IDM^\t\n ", [&](char op, unsigned long n) {
+        if (op == 'M') { index += (int)n; curIndex += (int)n; }
+        else if (op == 'I') {
+            unsigned long i = strandNo == 0 ? (unsigned long)index : readLength - index - 1;
+            errorProb = errorProb * p.inPosDist[i] * p.inLengthDist[n - 1] / (1 - p.errorPosDist[i] - p.inPosDist[i] - p.delPosDist[i]);
+            inserts[curIndex] = (int)n;
+            index += (int)n;
+        } else if (op == 'D') {
+            unsigned long i = strandNo == 0 ? (unsigned long)index : readLength - index - 1;
+            errorProb = errorProb * p.delPosDist[i] * p.delLengthDist[n - 1] / (1 - p.errorPosDist[i] - p.inPosDist[i] - p.delPosDist[i]);
+        }
+    });
+    walk_md(s.md, inserts, read, [&](int idx, int cur, char from, char to) {
+        int i = strandNo == 0 ? idx - 1 + cur : (int)readLength - idx - cur;
+        errorProb = errorProb * p.errorPosDist[i] / (1 - p.errorPosDist[i] - p.inPosDist[i] - p.delPosDist[i]);
+        int f = b5(from), t = b5(to);
+        if (f != t) errorProb *= p.baseErrorRates[f] * p.errorTypeProbs[f][t];
+    });
+    return errorProb;
+}
+
+}  // namespace
+
+bool build_model(const RunArgs &a, const Scaffold &sc, Model &out, std::string &err) {
+    Counts c;
+    long totalCount = 0, unCount = 0;
+    {
+        FILE *f = fopen((a.tmp + "stat.txt").c_str(), "r");
+        if (!f) { err = "can't open stat.txt"; return false; }
+        int ok = fscanf(f, "%ld %ld %d %d", &totalCount, &unCount, &c.L, &c.MAX_INSERT_SIZE);
+        fclose(f);
+        if (ok != 4 || c.L <= 0) { err = "malformed stat.txt"; return false; }
+    }
+    c.MAX_INSERT_SIZE = c.MAX_INSERT_SIZE > 20000 ? c.MAX_INSERT_SIZE : 20000;
+    c.maxInsertSize = c.MAX_INSERT_SIZE;
+    c.insertCounts.assign(c.maxInsertSize, 1);
+    for (auto &r : c.errorTypes) for (long &v : r) v = 1;
+    for (long &v : c.baseCounts) v = 1;
+    c.errorPos.assign(c.L, 1); c.inPos.assign(c.L, 1); c.inLengths.assign(c.L, 1); c.delPos.assign(c.L, 1); c.delLengths.assign(c.L, 1);
+    c.readLengths.assign(c.L, 0);
+    std::string noErrorCigar = std::to_string(c.L) + "M";
+    double inputMean = a.setinputmean == 1 ? a.isz : 0;
+
+    // pass 1 (Figbird.cpp:7110-7128)
+    FILE *mf = fopen(a.mapFile.c_str(), "r");
+    if (!mf) { err = "Can't open map file"; return false; }
+    char line[kMaxRec];
+    while (fgets(line, kMaxRec, mf)) {
+        if (line[0] == '@') continue;
+        SamCols s; split_sam(line, s);
+        if (!s.ok) continue;
+        if (s.nh == 1 && s.md[0] && s.md[5] != '^') {
+            long contigNo = atol(s.rname);
+            if (contigNo < 0 || contigNo >= sc.n()) { fclose(mf); err = "myout.sam: contig index out of range"; return false; }
+            if ((int)strlen(s.seq) > c.L) { fclose(mf); err = "myout.sam: read longer than maxReadLength"; return false; }
+            if ((double)(sc.off[contigNo + 1] - sc.off[contigNo]) > inputMean) update_insert_counts(c, s.tlen);
+            count_errors(c, s, noErrorCigar);
+            c.uniqueMappedReads++;
+        }
+    }
+    Probs p;
+    compute_probabilities(c, p);
+
+    // pass 2: gapProbs histogram (computeLikelihood, :1156-1376); only what feeds gapProbCutOff is kept
+    rewind(mf);
+    std::vector<long> gapProbs(1000, 0);
+    {
+        char l1[kMaxRec], l2[kMaxRec];
+        std::vector<long> effLen(c.maxInsertSize, -1);
+        auto effective = [&](int ins) -> long {
+            auto calc = [&](int v) { long e = 0; for (int64_t i = 0; i < sc.n(); i++) { long cl = (long)(sc.off[i + 1] - sc.off[i]); if (cl >= v) e += (cl - v + 1); } return e; };
+            if (ins < 0) return (long)sc.seq.size();
+            if (ins >= c.maxInsertSize) return calc(ins);
+            if (effLen[ins] == -1) effLen[ins] = calc(ins);
+            return effLen[ins];
+        };
+        long double sum = 0, logsum = 0, gapProb = 0, tempProb = 0;
+        std::string pre1 = "*", pre2 = "*";
+        while (fgets(l1, kMaxRec, mf)) {
+            if (l1[0] == '@') continue;
+            if (!fgets(l2, kMaxRec, mf)) break;
+            SamCols s1, s2; split_sam(l1, s1); split_sam(l2, s2);
+            if (!s1.ok || !s2.ok) continue;
+            int insertSize = std::max(s1.tlen, s2.tlen);
+            long double insertSizeProb = 0;
+            if (insertSize >= 0 && insertSize < c.maxInsertSize) insertSizeProb = p.insertLengthDist[insertSize];
+            if (insertSizeProb == 0) insertSizeProb = 1 / (double)c.uniqueMappedReads;
+            long double e1 = error_prob(p, s1), e2 = error_prob(p, s2);
+            long double prob = (1 / (long double)(effective(insertSize))) * insertSizeProb * e1 * e2;
+            bool same = pre1 == s1.qname && pre2 == s2.qname;
+            if (same) {
+                if (tempProb < prob) { tempProb = prob; gapProb = e2; }
+                sum += prob;
+            } else {
+                if (pre1 != "*" && pre2 != "*") {
+                    if (sum < 1e-320 || std::isnan(sum)) sum = 1e-320;
+                    logsum += log10l(sum);
+                    int gapIndex = (int)(-log10l(gapProb));
+                    gapIndex++;
+                    if (gapIndex < 1000 && gapIndex >= 0) gapProbs[gapIndex]++; else gapProbs[999]++;
+                }
+                sum = prob; tempProb = prob; gapProb = e2;
+            }
+            pre1 = s1.qname; pre2 = s2.qname;
+            if (std::isinf(logsum)) { fclose(mf); err = "model likelihood overflow (reference exits here)"; return false; }
+        }
+    }
+    fclose(mf);
+    long gapProbSum = 0, gapProbCount = 0;
+    for (long v : gapProbs) gapProbSum += v;
+    int cutoff = 0;
+    for (int i = 0; i < 1000; i++) { gapProbCount += gapProbs[i]; if (gapProbCount >= .8 * gapProbSum) { cutoff = i; break; } }
+
+    out.errorPosDist = p.errorPosDist; out.inPosDist = p.inPosDist; out.delPosDist = p.delPosDist;
+    out.insertLengthDistSmoothed = p.smoothed;
+    for (int i = 0; i < 5; i++) for (int j = 0; j < 5; j++) out.errorTypeProbs[i * 5 + j] = p.errorTypeProbs[i][j];
+    out.maxReadLength = c.L; out.maxInsertSize = c.maxInsertSize; out.cutoff = cutoff;
+    out.insertSizeMean = p.mean; out.leftSD = p.leftSD; out.rightSD = p.rightSD;
+    out.Tmin = std::max((int)(p.mean - 3 * p.leftSD), 1);                       // :7193-7200
+    out.Tmax = std::min((int)(p.mean + 3 * p.rightSD), c.maxInsertSize);
+    if (a.partial_flag) { out.Tmin -= a.partial_len; out.Tmax += a.partial_len; }
+    return true;
+}
+
+void Model::fill(fig_model &m, const RunArgs &a) const {
+    memset(&m, 0, sizeof(m));
+    m.max_read_length = maxReadLength;
+    m.error_pos_dist = errorPosDist.data(); m.in_pos_dist = inPosDist.data(); m.del_pos_dist = delPosDist.data();
+    for (int i = 0; i < 25; i++) m.error_type_probs[i] = errorTypeProbs[i];
+    m.insert_len_dist_smoothed = insertLengthDistSmoothed.data(); m.max_insert_size = maxInsertSize;
+    m.insert_threshold_min = Tmin; m.insert_threshold_max = Tmax; m.gap_prob_cutoff = cutoff;
+    m.partial_flag = a.partial_flag; m.unmapped_flag = a.unmapped; m.script_itr = a.script_itr; m.max_distance = a.D;
+    m.read_length = a.read_length; m.neg_overlap = a.neg_overlap; m.partial_len = a.partial_len; m.unm_limit = a.unm_limit;
+}
+
+// ------------------------------------------------------------------ per-gap inputs
+static bool read_lines(const std::string &path, std::vector<std::string> &out) {
+    out.clear();
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char buf[kMaxRec];
+    while (fgets(buf, kMaxRec, f)) out.emplace_back(buf);
+    fclose(f);
+    return true;
+}
+
+static char comp(char ch) {                 // reverse(), Figbird.cpp:1427-1449
+    switch (ch) { case 'A': case 'a': return 'T'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; case 'T': case 't': return 'A'; default: return 'N'; }
+}
+
+bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &B, std::string &err) {
+    std::vector<std::string> gi, st2;
+    if (!read_lines(a.tmp + "gapInfo.txt", gi)) { err = "Couldn't open gapinfo"; return false; }
+    if (!read_lines(a.tmp + "stat2.txt", st2)) { err = "Couldn't open stat2.txt"; return false; }
+    size_t ng = std::min(gi.size(), st2.size());        // the per-gap loop reads both files in lock step (:7329)
+    B = Batch();
+    B.u_read_off.push_back(0); B.p_read_off.push_back(0); B.u_seq_off.push_back(0); B.p_seq_off.push_back(0);
+    for (size_t g = 0; g < ng; g++) {
+        std::vector<char> b1(gi[g].begin(), gi[g].end()); b1.push_back(0);
+        char *sv = nullptr;
+        char *t = strtok_r(b1.data(), "\t", &sv); int contig = t ? atoi(t) : 0;
+        t = strtok_r(nullptr, "\t", &sv); long start = t ? atol(t) : 0;
+        t = strtok_r(nullptr, "\t\n", &sv); int len = t ? atoi(t) : 0;
+        if (contig < 0 || contig >= sc.n()) { err = "gapInfo.txt: contig index out of range"; return false; }
+        B.gap_contig.push_back(contig); B.gap_start.push_back(start); B.gap_len.push_back(len);
+        std::vector<char> b2(st2[g].begin(), st2[g].end()); b2.push_back(0);
+        sv = nullptr;
+        for (int k = 0; k < 3; k++) { t = strtok_r(k == 0 ? b2.data() : nullptr, "\t", &sv); B.gap_stat2.push_back(t ? atoi(t) : 0); }
+        int fillflag = 1;
+        std::string gs = std::to_string(g);
+        std::vector<std::string> lines;
+        if (a.unmapped == 1) {
+            // findcount_file(...,0) :6686-6711 then parseUnmapped :5661-5767
+            if (!read_lines(a.gapsDir + "gaps_" + gs + ".sam", lines)) { err = "missing gaps_" + gs + ".sam"; return false; }
+            long pairs = (long)(lines.size() / 2);
+            int r_count1 = (int)pairs;
+            if (pairs > kReadCap) { B.messages.push_back("Gap = " + gs + "\tReads = " + std::to_string(pairs)); r_count1 = kReadCap; fillflag = -1; }
+            int r_c = 0, total_read = 0;
+            size_t li = 0;
+            while (li < lines.size()) {
+                const std::string &l1 = lines[li++];
+                if (!l1.empty() && l1[0] == '@') continue;
+                if (l1.size() < 60) { B.messages.push_back("unknown problem in sam, skipping read no - " + std::to_string(r_c) + " for gap - " + gs); continue; }
+                if (li >= lines.size()) break;
+                const std::string &l2 = lines[li++];
+                if (r_c >= r_count1) break;
+                std::vector<char> c1(l1.begin(), l1.end()); c1.push_back(0);
+                std::vector<char> c2(l2.begin(), l2.end()); c2.push_back(0);
+                sv = nullptr;
+                strtok_r(c1.data(), "\t", &sv);
+                t = strtok_r(nullptr, "\t", &sv); int flag = t ? atoi(t) : 0;
+                strtok_r(nullptr, "\t", &sv);
+                t = strtok_r(nullptr, "\t", &sv); int pos = t ? atoi(t) : 0;
+                sv = nullptr;
+                strtok_r(c2.data(), "\t", &sv);
+                for (int k = 0; k < 5; k++) strtok_r(nullptr, "\t", &sv);
+                char *rs = strtok_r(nullptr, "\t", &sv);
+                std::string seq = rs ? rs : "";
+                while (!seq.empty() && (seq.back() == '\n' || seq.back() == '\r')) seq.pop_back();
+                bool fwd_anchor = ((flag & 16) >> 4) == 0;
+                if (fwd_anchor) { std::string rc(seq.size(), 'N'); for (size_t i = 0; i < seq.size(); i++) rc[seq.size() - 1 - i] = comp(seq[i]); seq = rc; }
+                if (seq.empty()) { err = "gaps_" + gs + ".sam: empty mate sequence"; return false; }
+                B.u_anchor_pos.push_back(pos); B.u_is_reverse.push_back(fwd_anchor ? 1 : 0);
+                B.u_seq += seq; B.u_seq_off.push_back((int64_t)B.u_seq.size());
+                r_c++; total_read++;
+                if (total_read == kReadCap) break;
+            }
+        }
+        B.u_read_off.push_back((int64_t)B.u_anchor_pos.size());
+        if (!read_lines(a.gapsDir + "partial_gaps_" + gs + ".sam", lines)) { err = "missing partial_gaps_" + gs + ".sam (the reference fopen()s it unconditionally)"; return false; }
+        size_t keep = std::min(lines.size(), (size_t)kReadCap + 1);
+        for (size_t k = 0; k < keep; k++) {
+            std::vector<char> c1(lines[k].begin(), lines[k].end()); c1.push_back(0);
+            sv = nullptr;
+            char *seq = strtok_r(c1.data(), "\t", &sv);
+            t = strtok_r(nullptr, "\t", &sv); int clip = t ? atoi(t) : 0;
+            t = strtok_r(nullptr, "\t", &sv); int match = t ? atoi(t) : 0;
+            t = strtok_r(nullptr, "\t", &sv); int pos = t ? atoi(t) : 0;
+            strtok_r(nullptr, "\t", &sv);
+            t = strtok_r(nullptr, "\t", &sv); int ref = t ? atoi(t) : 0;
+            char *q = strtok_r(nullptr, "\t", &sv);
+            std::string s = seq ? seq : "", qs = q ? q : "";
+            while (!s.empty() && (s.back() == '\n' || s.back() == '\r')) s.pop_back();
+            while (!qs.empty() && (qs.back() == '\n' || qs.back() == '\r')) qs.pop_back();
+            if (s.empty()) { err = "partial_gaps_" + gs + ".sam: empty sequence"; return false; }
+            qs.resize(s.size(), 'I');
+            B.p_clipped_index.push_back(clip); B.p_match.push_back(match); B.p_pos.push_back(pos); B.p_ref_pos.push_back(ref);
+            B.p_seq += s; B.p_qual += qs; B.p_seq_off.push_back((int64_t)B.p_seq.size());
+        }
+        B.p_read_off.push_back((int64_t)B.p_clipped_index.size());
+        B.gap_fillflag.push_back(fillflag);
+    }
+    return true;
+}
+
+void Batch::view(fig_gap_batch &b, const Scaffold &sc) const {
+    memset(&b, 0, sizeof(b));
+    b.n_gaps = (int64_t)gap_contig.size();
+    b.n_contigs = sc.n(); b.contig_off = sc.off.data(); b.contig_seq = sc.seq.data();
+    b.gap_contig = gap_contig.data(); b.gap_start = gap_start.data(); b.gap_len = gap_len.data();
+    b.gap_stat2 = gap_stat2.data(); b.gap_fillflag = gap_fillflag.data();
+    b.u_read_off = u_read_off.data(); b.u_anchor_pos = u_anchor_pos.data(); b.u_is_reverse = u_is_reverse.data();
+    b.u_seq_off = u_seq_off.data(); b.u_seq = u_seq.data();
+    b.p_read_off = p_read_off.data(); b.p_clipped_index = p_clipped_index.data(); b.p_match = p_match.data();
+    b.p_pos = p_pos.data(); b.p_ref_pos = p_ref_pos.data(); b.p_seq_off = p_seq_off.data(); b.p_seq = p_seq.data(); b.p_qual = p_qual.data();
+}
+
+// ------------------------------------------------------------------ outputs
+bool write_gapout(const RunArgs &a, const Batch &b, const Results &r, std::string &err) {
+    FILE *f = fopen((a.tmp + "gapout.txt").c_str(), "w");
+    if (!f) { err = "can't write gapout.txt"; return false; }
+    for (size_t g = 0; g < b.gap_contig.size(); g++) {
+        int n = r.filled_len[g];
+        fprintf(f, "%d\t%d\t%ld\t%d\t%d\t", (int)g, b.gap_contig[g], (long)b.gap_start[g], b.gap_len[g], n);
+        if (n > 0) fwrite(r.str.data() + r.str_off[g], 1, (size_t)n, f);
+        fputc('\n', f);
+    }
+    fclose(f);
+    return true;
+}
+
+bool write_draw(const RunArgs &a, const Batch &b, const Results &r, std::string &err) {
+    FILE *f = fopen((a.tmp + "draw.txt").c_str(), "w");
+    if (!f) { err = "can't write draw.txt"; return false; }
+    if (r.draw_len.empty()) { fclose(f); return true; }
+    int readlen = a.read_length;
+    int64_t nu = (int64_t)b.u_anchor_pos.size();
+    auto header = [&](int g, int length) {
+        for (int i = 0; i < readlen; i++) fputc(' ', f);
+        fprintf(f, "====================+Gap = %d starting,length = %d===============================\n", g, length);
+        for (int i = 0; i < readlen; i++) fputc(' ', f);
+        for (int i = 0; i < length; i++) fputc('N', f);
+        fputc('\n', f);
+    };
+    auto readline = [&](const char *s, int slen, int readno, int length, int isz, char type) {
+        for (int i = 0; i < readlen + length; i++) fputc(' ', f);
+        fwrite(s, 1, (size_t)slen, f);
+        fprintf(f, "[%d %d isz = %d %c]\n", readno, length, isz, type);
+    };
+    for (size_t g = 0; g < b.gap_contig.size(); g++) {
+        int lu = r.draw_len[g * 2], lp = r.draw_len[g * 2 + 1];
+        if (lu >= 0) {
+            header((int)g, lu);
+            int gapoffset = lu - b.gap_len[g];
+            for (int64_t k = b.u_read_off[g]; k < b.u_read_off[g + 1]; k++) {
+                if (r.draw_pos[k] == INT32_MIN) continue;
+                long pos1 = b.u_anchor_pos[k];
+                if (!(pos1 < b.gap_start[g])) pos1 += gapoffset;
+                char type = pos1 < b.gap_start[g] ? 'I' : 'E';
+                readline(b.u_seq.data() + b.u_seq_off[k], (int)(b.u_seq_off[k + 1] - b.u_seq_off[k]), (int)(k - b.u_read_off[g]), r.draw_pos[k], r.draw_isz[k], type);
+            }
+        }
+        if (lp >= 0) {
+            header((int)g, lp);
+            for (int64_t k = b.p_read_off[g]; k < b.p_read_off[g + 1]; k++) {
+                if (r.draw_pos[nu + k] == INT32_MIN) continue;
+                readline(b.p_seq.data() + b.p_seq_off[k], (int)(b.p_seq_off[k + 1] - b.p_seq_off[k]), (int)(k - b.p_read_off[g]), r.draw_pos[nu + k], r.draw_isz[nu + k], 'P');
+            }
+        }
+    }
+    fclose(f);
+    return true;
+}
+
+bool write_scaffold(const RunArgs &a, const Scaffold &sc, const Batch &b, const Results &r, std::string &err) {
+    FILE *out = fopen((a.tmp + "filledContigs.fa").c_str(), "w");
+    FILE *nf = fopen((a.tmp + "Ncount.txt").c_str(), "w");
+    if (!out || !nf) { err = "can't write filledContigs.fa / Ncount.txt"; if (out) fclose(out); if (nf) fclose(nf); return false; }
+    std::vector<int> gtf(r.gaptofill.begin(), r.gaptofill.end());      // consumed like FillGaps.cpp's array (:900-904)
+    size_t ng = b.gap_contig.size();
+    int nStart = 0, gap_count = -1;
+    long newNcount = 0;
+    size_t next_gap = 0;
+    std::string gapString;              // keeps the previous gap's string when a gap closes to length 0 (:861-870)
+    int gapStringLength = 0;
+    std::string buf;
+    for (int64_t i = 0; i < sc.n(); i++) {
+        const char *cs = sc.seq.data() + sc.off[i];
+        int64_t n = sc.off[i + 1] - sc.off[i];
+        fprintf(out, ">%s\n", sc.names[i].c_str());
+        buf.clear();
+        for (int64_t j = 0; j < n; j++) {
+            bool isN = cs[j] == 'N' || cs[j] == 'n';
+            if (isN && nStart == 0) { nStart = 1; gap_count++; }
+            if (!isN || j == n - 1) {
+                if (nStart == 1) {
+                    if (next_gap < ng) {
+                        gapStringLength = r.filled_len[next_gap];
+                        if (gapStringLength > 0) gapString.assign(r.str.data() + r.str_off[next_gap], (size_t)gapStringLength);
+                        next_gap++;
+                    }
+                    for (char ch : gapString) if (ch == 'N') newNcount++;
+                    fwrite(buf.data(), 1, buf.size(), out);
+                    if (gapStringLength > 0) fwrite(gapString.data(), 1, gapString.size(), out);
+                    buf.clear();
+                    nStart = 0;
+                }
+                if (gap_count >= 0 && gap_count < (int)gtf.size() && gtf[gap_count] > 0) gtf[gap_count]--;
+                else buf.push_back(cs[j]);
+            }
+        }
+        fwrite(buf.data(), 1, buf.size(), out);
+        fputc('\n', out);
+    }
+    fprintf(nf, "%d", newNcount == 0 ? 0 : 1);                          // FillGaps.cpp:920-922
+    fclose(out); fclose(nf);
+    return true;
+}
+
+}  // namespace fighost

@@ -1,0 +1,98 @@
+// figfill -- drop-in for the reference's gap-fill stage.  RunFigbird.sh:352/:480 runs
+//   g++ -std=c++11 -pthread FillGaps.cpp && ./a.out <15 args>
+// figfill takes the same 15 positional arguments (FillGaps.cpp:419-433), reads the same
+// files Preprocess.cpp left behind and writes the same outputs (Temp/filledContigs.fa,
+// gapout.txt, draw.txt, Ncount.txt) -- but instead of fanning out `g++ Figbird.cpp`
+// processes it builds the model once, packs every gap into one batch and hands it to the
+// MI355X engine through the C ABI of include/figbird_hip.h.  Exit codes follow the
+// reference: message on stderr + exit(1).
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <chrono>
+
+#include "fig_host.h"
+
+using namespace fighost;
+
+static int fail(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
+
+int main(int argc, char **argv) {
+    if (argc < 16) {
+        fprintf(stderr, "usage: figfill <contigs.fa> <maxDistance> <readLen> <scriptItr> <partialFlag> <unmapped> <numThreads> "
+                        "<myout.sam> <tmp/> <gaps/> <negOverlap> <partialReadLen> <trim> <setInputMean> <insertSize>\n");
+        return 1;
+    }
+    RunArgs a;
+    a.contigFile = argv[1]; a.D = atoi(argv[2]); a.read_length = atoi(argv[3]); a.script_itr = atoi(argv[4]);
+    a.partial_flag = atoi(argv[5]); a.unmapped = atoi(argv[6]); a.num_threads = atoi(argv[7]); a.mapFile = argv[8];
+    a.tmp = argv[9]; a.gapsDir = argv[10]; a.neg_overlap = atoi(argv[11]); a.partial_len = atoi(argv[12]);
+    a.trim = atoi(argv[13]); a.setinputmean = atoi(argv[14]); a.isz = atoi(argv[15]);
+    a.unm_limit = 400;                                   // gapthresh, FillGaps.cpp:22
+    const char *dev_env = getenv("FIGFILL_DEVICE");
+    int device = dev_env ? atoi(dev_env) : 0;
+    auto t0 = std::chrono::steady_clock::now();
+
+    std::string err;
+    Scaffold sc;
+    if (!load_scaffold(a.contigFile, sc, err)) return fail(err);
+    Batch B;
+    if (!load_batch(a, sc, B, err)) return fail(err);
+    printf("Total # of gaps = %zu\n", B.gap_contig.size());
+    for (const std::string &m : B.messages) printf("%s\n", m.c_str());
+    Model M;
+    if (!build_model(a, sc, M, err)) return fail(err);
+
+    fig_model fm; M.fill(fm, a);
+    fig_gap_batch fb; B.view(fb, sc);
+    fig_ctx *ctx = nullptr;
+    int rc = fig_ctx_create(device, &ctx);
+    if (rc) return fail(std::string("figfill: fig_ctx_create: ") + fig_strerror(rc));
+    rc = fig_ctx_set_model(ctx, &fm);
+    if (rc) { fig_ctx_destroy(ctx); return fail(std::string("figfill: fig_ctx_set_model: ") + fig_strerror(rc)); }
+
+    Results R;
+    int64_t ng = fb.n_gaps;
+    int64_t cap = fig_results_capacity(&fm, &fb);
+    R.filled_len.assign(ng, 0); R.gaptofill.assign(ng, 0); R.str_off.assign(ng + 1, 0); R.str.assign((size_t)std::max<int64_t>(cap, 1), 'N');
+    int64_t nr = (int64_t)B.u_anchor_pos.size() + (int64_t)B.p_pos.size();
+    R.draw_pos.assign((size_t)std::max<int64_t>(nr, 1), INT32_MIN); R.draw_isz.assign((size_t)std::max<int64_t>(nr, 1), 0); R.draw_len.assign((size_t)std::max<int64_t>(ng * 2, 1), -1);
+    fig_gap_results fr; memset(&fr, 0, sizeof(fr));
+    fr.filled_len = R.filled_len.data(); fr.gaptofill = R.gaptofill.data(); fr.str_off = R.str_off.data();
+    fr.str = &R.str[0]; fr.str_capacity = (int64_t)R.str.size();
+    fr.draw_pos = R.draw_pos.data(); fr.draw_isz = R.draw_isz.data(); fr.draw_len = R.draw_len.data();
+    // optional candidate trace for the parity tests (FIGFILL_TRACE=<file>)
+    const char *trace = getenv("FIGFILL_TRACE");
+    std::vector<int32_t> dn, di; std::vector<double> dl;
+    const int maxc = 2048;
+    if (trace) {
+        dn.assign((size_t)std::max<int64_t>(ng, 1), 0); di.assign((size_t)std::max<int64_t>(ng, 1) * maxc * 3, 0); dl.assign((size_t)std::max<int64_t>(ng, 1) * maxc, 0);
+        fr.dbg_max_cand = maxc; fr.dbg_n_cand = dn.data(); fr.dbg_cand_i = di.data(); fr.dbg_cand_lik = dl.data();
+    }
+    rc = fig_fill_gaps(ctx, &fb, &fr);
+    fig_stats st; memset(&st, 0, sizeof(st)); fig_get_stats(ctx, &st);
+    fig_ctx_destroy(ctx);
+    if (rc) return fail(std::string("figfill: fig_fill_gaps: ") + fig_strerror(rc));
+
+    if (!write_gapout(a, B, R, err)) return fail(err);
+    if (!write_draw(a, B, R, err)) return fail(err);
+    if (!write_scaffold(a, sc, B, R, err)) return fail(err);
+    if (trace) {
+        FILE *f = fopen(trace, "w");
+        if (f) {
+            fprintf(f, "MODEL\t%d\t%d\t%d\t%a\t%a\t%a\n", M.cutoff, M.Tmin, M.Tmax, M.insertSizeMean, M.leftSD, M.rightSD);
+            for (int64_t g = 0; g < ng; g++)
+                for (int k = 0; k < dn[g] && k < maxc; k++)
+                    fprintf(f, "CAND\t%d\t%d\t%d\t%a\t%d\n", (int)g, di[(g * maxc + k) * 3], di[(g * maxc + k) * 3 + 1], dl[g * maxc + k], di[(g * maxc + k) * 3 + 2]);
+            fprintf(f, "STATS\t%lld\t%.17g\n", (long long)st.place_calls, st.alg_flops);
+            fclose(f);
+        }
+    }
+    double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    printf("Time taken = %g seconds (device kernels %.3f ms, %lld placeReads calls)\n", secs, st.kernel_ms, (long long)st.place_calls);
+    printf("======================================\n");
+    printf("Iteration %d ends successfully\n", a.script_itr);
+    printf("======================================\n");
+    return 0;
+}

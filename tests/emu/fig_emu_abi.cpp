@@ -1,0 +1,130 @@
+// fig_emu_abi.cpp -- TEST INFRASTRUCTURE ONLY (CPU unit tests, `-m "not gpu"`).
+//
+// Implements the C ABI of include/figbird_hip.h by compiling the device engine
+// (figbird_amd/csrc/fig_engine.h) for the host with FIG_EMU: ONE emulated lane per
+// workgroup, barriers are no-ops.  It lets the CPU test-suite check the engine's control
+// logic, packing and host plumbing against the oracle without a GPU.  It is never linked
+// into libfighip.so or figfill; the product fails with FIG_ENODEV when no GPU is present.
+#define FIG_EMU 1
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+#include "../../include/figbird_hip.h"
+#include "../../figbird_amd/csrc/fig_engine.h"
+#include "../../figbird_amd/csrc/fig_pack.h"
+
+struct fig_ctx {
+    bool have_model = false;
+    fig_model hm;
+    FigDevModel dm;
+    std::vector<double> e, ome, m3, insd, qtab;
+    bool have_batch = false;
+    FigPacked K;
+    fig_stats stats;
+};
+
+extern "C" int fig_version(void) { return FIG_ABI_VERSION; }
+extern "C" const char *fig_strerror(int code) { (void)code; return "emu"; }
+extern "C" int fig_ctx_create(int, fig_ctx **out) { *out = new fig_ctx(); memset(&(*out)->stats, 0, sizeof(fig_stats)); return FIG_OK; }
+extern "C" void fig_ctx_destroy(fig_ctx *c) { delete c; }
+extern "C" void fig_batch_free(fig_ctx *c) { if (c) { c->K = FigPacked(); c->have_batch = false; } }
+extern "C" int fig_get_stats(const fig_ctx *c, fig_stats *o) { *o = c->stats; return FIG_OK; }
+extern "C" int64_t fig_results_capacity(const fig_model *m, const fig_gap_batch *b) { return fig_pack_results_capacity(m, b); }
+
+extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
+    if (!ctx || !m) return FIG_EINVAL;
+    if (m->max_read_length <= 0 || m->max_read_length > FIG_MAX_READLEN) return FIG_EUNSUP;
+    if (m->partial_flag && m->unmapped_flag) return FIG_EUNSUP;
+    int L = m->max_read_length;
+    ctx->hm = *m;
+    ctx->e.assign(m->error_pos_dist, m->error_pos_dist + L);
+    ctx->ome.resize(L); ctx->m3.resize(L);
+    for (int k = 0; k < L; k++) {
+        volatile double a = 1 - m->error_pos_dist[k]; ctx->ome[k] = a;
+        volatile double b = 1 - m->error_pos_dist[k] - m->in_pos_dist[k] - m->del_pos_dist[k]; ctx->m3[k] = b;
+    }
+    ctx->insd.assign(m->insert_len_dist_smoothed, m->insert_len_dist_smoothed + m->max_insert_size);
+    ctx->insd.push_back(0.0);
+    ctx->qtab.resize(256);
+    for (int c = 0; c < 256; c++) { int Q = c - 33; ctx->qtab[c] = pow(10, -Q / 10.0); }
+    FigDevModel &dm = ctx->dm;
+    dm.L = L; dm.Tmin = m->insert_threshold_min; dm.Tmax = m->insert_threshold_max; dm.cutoff = m->gap_prob_cutoff;
+    dm.partial_flag = m->partial_flag; dm.unmapped = m->unmapped_flag; dm.script_itr = m->script_itr; dm.D = m->max_distance;
+    dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
+    dm.max_insert = m->max_insert_size;
+    for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
+    dm.e = ctx->e.data(); dm.ome = ctx->ome.data(); dm.m3 = ctx->m3.data(); dm.insd = ctx->insd.data(); dm.qtab = ctx->qtab.data();
+    ctx->have_model = true;
+    return FIG_OK;
+}
+
+extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
+    if (!ctx || !b || !ctx->have_model) return FIG_EINVAL;
+    ctx->K = FigPacked();
+    int rc = fig_pack(&ctx->hm, b, sizeof(FigState), ctx->K);
+    if (rc) return rc;
+    ctx->have_batch = true;
+    return FIG_OK;
+}
+
+extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
+    if (!ctx || !out || !ctx->have_batch) return FIG_EINVAL;
+    FigPacked &K = ctx->K;
+    int64_t ng = K.n_gaps;
+    FigDevBatch B; memset(&B, 0, sizeof(B));
+    B.n_gaps = ng; B.gaps = K.gaps.data(); B.order = K.order.data();
+    B.u.pos = K.u_pos.data(); B.u.aux = K.u_aux.data(); B.u.len = K.u_len.data(); B.u.woff = K.u_woff.data();
+    B.p.pos = K.p_pos.data(); B.p.aux = K.p_aux.data(); B.p.clip = K.p_clip.data(); B.p.refpos = K.p_ref.data();
+    B.p.len = K.p_len.data(); B.p.woff = K.p_woff.data(); B.p.qoff = K.p_qoff.data();
+    B.packed = K.packed.data(); B.qual = K.qual.data(); B.flank = K.flank.data();
+    std::vector<int32_t> fl(ng + 1, 0), gtf(ng + 1, 0);
+    std::vector<char> str((size_t)K.str_total + 8, 'N');
+    B.filled_len = fl.data(); B.gaptofill = gtf.data(); B.str = str.data();
+    if (out->dbg_n_cand && out->dbg_cand_i && out->dbg_cand_lik && out->dbg_max_cand > 0) {
+        B.dbg_max_cand = out->dbg_max_cand; B.dbg_n_cand = out->dbg_n_cand; B.dbg_cand_i = out->dbg_cand_i; B.dbg_cand_lik = out->dbg_cand_lik;
+        for (int64_t g = 0; g < ng; g++) out->dbg_n_cand[g] = 0;
+    }
+    if (out->draw_pos && out->draw_isz && out->draw_len) { B.draw_pos = out->draw_pos; B.draw_isz = out->draw_isz; B.draw_len = out->draw_len; }
+    B.n_ureads = (int64_t)K.u_pos.size();
+    int32_t qh = 0; unsigned long long counters[8] = {0};
+    B.queue_head = &qh; B.counters = counters;
+    long long stride = fig_scratch_layout(nullptr, K.capG, K.capR, K.capP, K.capC, K.capW, nullptr);
+    std::vector<unsigned char> slab((size_t)stride + 64, 0);
+    B.scratch = slab.data(); B.scratch_stride = stride;
+    B.capG = K.capG; B.capR = K.capR; B.capP = K.capP; B.capC = K.capC;
+    for (const FigLaunchClass &c : K.classes) {
+        std::vector<double> lds((size_t)(9LL * c.capG + c.capW) + (sizeof(FigState) + c.capG + FIG_MAX_READLEN + 64) / 8 + 8, 0.0);
+        FigEng E;
+        E.tid = 0; E.nt = 1; E.M = &ctx->dm; E.B = &B; E.capG = c.capG; E.capW = c.capW; E.flops = 0;
+        fig_scratch_layout(slab.data(), K.capG, K.capR, K.capP, K.capC, c.capW, &E.scr);
+        double *lp = lds.data();
+        E.P = lp; lp += 4LL * c.capG; E.Q = lp; lp += 5LL * c.capG; E.wbuf = lp; lp += c.capW;
+        E.S = (FigState *)lp;
+        unsigned char *bp = (unsigned char *)(E.S + 1);
+        E.gs = bp; bp += ((c.capG + 7) & ~7); E.rb = bp;
+        for (int qi = c.q_begin; qi < c.q_end; qi++) { E.g = &K.gaps[K.order[qi]]; fig_fill_gap(E); }
+        counters[1] += E.flops;
+    }
+    ctx->stats.place_calls = (int64_t)counters[0]; ctx->stats.alg_flops = (double)counters[1];
+    ctx->stats.packed_bytes = K.packed_bytes(); ctx->stats.n_launches = (int)K.classes.size();
+    int64_t need = 0;
+    for (int64_t g = 0; g < ng; g++) { out->filled_len[g] = fl[g]; out->gaptofill[g] = gtf[g]; need += fl[g] > 0 ? fl[g] : 0; }
+    if (need > out->str_capacity) return FIG_ENOSPC;
+    int64_t o = 0;
+    for (int64_t g = 0; g < ng; g++) {
+        out->str_off[g] = o;
+        if (fl[g] > 0) { memcpy(out->str + o, str.data() + K.str_off[g], (size_t)fl[g]); o += fl[g]; }
+    }
+    out->str_off[ng] = o;
+    return FIG_OK;
+}
+
+extern "C" int fig_fill_gaps(fig_ctx *ctx, const fig_gap_batch *batch, fig_gap_results *out) {
+    int rc = fig_batch_upload(ctx, batch);
+    if (rc) return rc;
+    rc = fig_fill_resident(ctx, out);
+    fig_batch_free(ctx);
+    return rc;
+}

@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Dev tool: figfill (emu or real) vs oracle (fillgaps mode) on seeded cases."""
+import os, shutil, subprocess, sys, tempfile, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from figbird_amd import synth
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORA = os.path.join(ROOT, "oracle", "figbird_oracle")
+EMU = os.path.join(ROOT, "tests", "emu", "figfill_emu")
+
+def run_one(case, base, exe=EMU, verbose=True, trace=False):
+    shutil.rmtree(base, ignore_errors=True)
+    po = synth.write_case(case, os.path.join(base, "ora"))
+    pe = synth.write_case(case, os.path.join(base, "emu"))
+    env = dict(os.environ)
+    if trace:
+        env["FIG_ORACLE_TRACE"] = os.path.join(base, "ora.trace"); env["FIG_ORACLE_TRACE_LEVEL"] = "1"
+        env["FIGFILL_TRACE"] = os.path.join(base, "emu.trace")
+    t = time.time(); ro = subprocess.run([ORA, "fillgaps"] + synth.fillgaps_argv(case, po), capture_output=True, text=True, env=env); to = time.time() - t
+    t = time.time(); re_ = subprocess.run([exe] + synth.fillgaps_argv(case, pe), capture_output=True, text=True, env=env); te = time.time() - t
+    ok = ro.returncode == 0 and re_.returncode == 0
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        a = open(po["tmp"] + fn).read() if os.path.exists(po["tmp"] + fn) else None
+        b = open(pe["tmp"] + fn).read() if os.path.exists(pe["tmp"] + fn) else None
+        if a != b:
+            ok = False
+            if verbose:
+                print("  DIFF", fn)
+                if a and b:
+                    for x, y in zip(a.splitlines(), b.splitlines()):
+                        if x != y: print("   ora:", x[:200]); print("   emu:", y[:200]); break
+    if verbose:
+        print(f"{case.name}: {'OK' if ok else 'MISMATCH'} oracle {to:.2f}s emu {te:.2f}s rc {ro.returncode}/{re_.returncode} {re_.stderr[-300:]}")
+    return ok
+
+if __name__ == "__main__":
+    base = tempfile.mkdtemp(prefix="figemu_")
+    cases = [
+        synth.make_case("p_small", 2, "partial", [(3000, 30), (6000, 120), (9000, 10)], insert_mean=180, insert_sd=10, coverage=30),
+        synth.make_case("u_small", 1, "unmapped", [(3000, 30), (6000, 600)], coverage=20),
+    ]
+    ok = True
+    for c in cases: ok &= run_one(c, os.path.join(base, c.name), trace=True)
+    print(base)
+    sys.exit(0 if ok else 1)
