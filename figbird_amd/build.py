@@ -16,6 +16,7 @@ LIBDIR = os.path.join(PKG, "lib")
 BINDIR = os.path.join(PKG, "bin")
 LIB = os.path.join(LIBDIR, "libfighip.so")
 FIGFILL = os.path.join(BINDIR, "figfill")
+HOSTLIB = os.path.join(LIBDIR, "libfighost.so")
 EMU = os.path.join(ROOT, "tests", "emu", "figfill_emu")
 ORACLE = os.path.join(ROOT, "oracle", "figbird_oracle")
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
@@ -58,6 +59,8 @@ def build_figfill(force: bool = False) -> str:
         _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", FIGFILL,
               os.path.join(host, "figfill_main.cpp"), os.path.join(host, "fig_host.cpp"),
               "-L" + LIBDIR, "-lfighip", "-Wl,-rpath,$ORIGIN/../lib"])
+    if force or not _newer(HOSTLIB, srcs):
+        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", HOSTLIB, os.path.join(host, "fig_host.cpp")])
     return FIGFILL
 
 

@@ -585,3 +585,25 @@ bool write_scaffold(const RunArgs &a, const Scaffold &sc, const Batch &b, const 
 }
 
 }  // namespace fighost
+
+// ------------------------------------------------------------------ C wrappers (libfighost.so)
+// Used by the Python tests / bench to obtain the run-level model exactly as figfill builds it.
+extern "C" int fighost_build_model(const char *contig_file, const char *tmp_dir, const char *map_file, int partial_flag,
+                                   int partial_len, int setinputmean, int isz, int max_read_cap, int insd_cap,
+                                   double *e, double *ins, double *del, double *T25, double *insd, int *ints5, double *stats3) {
+    fighost::RunArgs a;
+    a.contigFile = contig_file; a.tmp = tmp_dir; a.mapFile = map_file; a.partial_flag = partial_flag; a.partial_len = partial_len;
+    a.setinputmean = setinputmean; a.isz = isz;
+    std::string err;
+    fighost::Scaffold sc;
+    if (!fighost::load_scaffold(a.contigFile, sc, err)) { fprintf(stderr, "%s\n", err.c_str()); return -1; }
+    fighost::Model M;
+    if (!fighost::build_model(a, sc, M, err)) { fprintf(stderr, "%s\n", err.c_str()); return -1; }
+    if (M.maxReadLength > max_read_cap || M.maxInsertSize > insd_cap) return -2;
+    for (int k = 0; k < M.maxReadLength; k++) { e[k] = M.errorPosDist[k]; ins[k] = M.inPosDist[k]; del[k] = M.delPosDist[k]; }
+    for (int i = 0; i < 25; i++) T25[i] = M.errorTypeProbs[i];
+    for (int i = 0; i < M.maxInsertSize; i++) insd[i] = M.insertLengthDistSmoothed[i];
+    ints5[0] = M.maxReadLength; ints5[1] = M.maxInsertSize; ints5[2] = M.Tmin; ints5[3] = M.Tmax; ints5[4] = M.cutoff;
+    stats3[0] = M.insertSizeMean; stats3[1] = M.leftSD; stats3[2] = M.rightSD;
+    return 0;
+}

@@ -381,3 +381,240 @@ def write_gaploads(paths: dict, gap_ids: List[int]) -> None:
     """tmp/gaploads.txt as FillGaps.cpp:313-334 writes it, for a single thread 0."""
     with open(paths["tmp"] + "gaploads.txt", "w") as f:
         f.write("".join(f"{g}\t" for g in gap_ids) + "\n")
+
+
+# =========================================================================================
+# In-memory batches for the C ABI (figbird_amd.api.GapBatch) -- used by tests and bench.py
+# =========================================================================================
+def case_to_batch(case: Case):
+    """Case -> GapBatch, applying what parseUnmapped does to each mate (Figbird.cpp:5727-5736):
+    reverse-complement it iff the anchor is on the forward strand."""
+    from .api import GapBatch
+    seq = "".join(s.upper() for s in case.scaffolds)
+    off = np.zeros(len(case.scaffolds) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in case.scaffolds])
+    u_off, u_pos, u_rev, u_soff, u_seq = [0], [], [], [0], []
+    p_off, p_clip, p_match, p_pos, p_ref, p_soff, p_seq, p_qual = [0], [], [], [], [], [0], [], []
+    fillflag = []
+    for g in case.gaps:
+        n = 0
+        if case.mode == "unmapped":
+            for r in g.unmapped[:3000]:
+                s = r.mate_seq_fastq if r.anchor_reverse else revcomp(r.mate_seq_fastq)
+                u_pos.append(r.anchor_pos1); u_rev.append(0 if r.anchor_reverse else 1)
+                u_seq.append(s); u_soff.append(u_soff[-1] + len(s)); n += 1
+        u_off.append(u_off[-1] + n)
+        fillflag.append(-1 if (case.mode == "unmapped" and len(g.unmapped) > 3000) else 1)
+        for r in g.partial[:3001]:
+            p_clip.append(r.clipped_index); p_match.append(r.match); p_pos.append(r.pos1); p_ref.append(r.mate_pos)
+            p_seq.append(r.seq); p_qual.append(r.qual); p_soff.append(p_soff[-1] + len(r.seq))
+        p_off.append(p_off[-1] + min(len(g.partial), 3001))
+    a8 = lambda s: np.frombuffer((s or "\0").encode(), dtype=np.uint8).copy()
+    i32 = lambda v: np.asarray(v if len(v) else [0], dtype=np.int32)
+    return GapBatch(
+        contig_off=off, contig_seq=a8(seq),
+        gap_contig=i32([g.contig for g in case.gaps]), gap_start=np.asarray([g.start for g in case.gaps], dtype=np.int64),
+        gap_len=i32([g.length for g in case.gaps]), gap_stat2=i32([x for g in case.gaps for x in g.stat2]),
+        gap_fillflag=i32(fillflag),
+        u_read_off=np.asarray(u_off, dtype=np.int64), u_anchor_pos=i32(u_pos), u_is_reverse=np.asarray(u_rev if u_rev else [0], dtype=np.uint8),
+        u_seq_off=np.asarray(u_soff, dtype=np.int64), u_seq=a8("".join(u_seq)),
+        p_read_off=np.asarray(p_off, dtype=np.int64), p_clipped_index=i32(p_clip), p_match=i32(p_match), p_pos=i32(p_pos),
+        p_ref_pos=i32(p_ref), p_seq_off=np.asarray(p_soff, dtype=np.int64), p_seq=a8("".join(p_seq)), p_qual=a8("".join(p_qual)))
+
+
+_COMP_LUT = np.full(256, ord("N"), dtype=np.uint8)
+for _a, _b in zip(b"ACGT", b"TGCA"):
+    _COMP_LUT[_a] = _b
+
+
+@dataclass
+class BenchSpec:
+    """The synthetic set of BASELINE.json / SURVEY.md §8(d): scaffolds of 50 kb, a gap every
+    ~5 kb, two libraries (frag 2x101 N(180,10) -> partial mode, jump 2x150 N(3500,350) ->
+    unmapped mode), 0.5 % substitutions, flat Q40, reads/gap ~ coverage-proportional with the
+    reference's 3000-read cap."""
+    mode: str = "unmapped"
+    read_len: int = 150
+    insert_mean: float = 3500.0
+    insert_sd: float = 350.0
+    err: float = 0.005
+    reads_per_gap_mean: float = 1000.0      # 1e8 reads / 1e5 gaps
+    gap_mix: str = "gage"                   # "gage" (<=30:20%,31-133:30%,134-400:25%,>400:25%) or "loguniform" [50,2000]
+    scaffold_len: int = 50000
+    gap_spacing: int = 5000
+    partial_cov: int = 24
+    frag_len: int = 101
+
+    @property
+    def max_distance(self) -> int:
+        return int(self.insert_mean) if self.mode == "partial" else int(1.15 * self.insert_mean)
+
+
+def _draw_gap_lengths(rng, n: int, mix: str) -> np.ndarray:
+    if mix == "loguniform":
+        return np.exp(rng.uniform(np.log(50), np.log(2000), size=n)).astype(np.int64)
+    u = rng.random(n)
+    out = np.empty(n, dtype=np.int64)
+    a = u < 0.20; b = (u >= 0.20) & (u < 0.50); c = (u >= 0.50) & (u < 0.75); d = u >= 0.75
+    out[a] = rng.integers(5, 31, size=int(a.sum()))
+    out[b] = rng.integers(31, 134, size=int(b.sum()))
+    out[c] = rng.integers(134, 401, size=int(c.sum()))
+    out[d] = np.exp(rng.uniform(np.log(401), np.log(2000), size=int(d.sum()))).astype(np.int64)
+    return out
+
+
+def make_bench_batch(seed: int, n_gaps: int, spec: BenchSpec, gap_lengths: Optional[np.ndarray] = None):
+    """Vectorised generator: returns (GapBatch, truth) with `truth[g]` the true gap sequence (uint8)."""
+    from .api import GapBatch
+    rng = np.random.default_rng(np.random.PCG64(seed))
+    L = spec.read_len
+    G = _draw_gap_lengths(rng, n_gaps, spec.gap_mix) if gap_lengths is None else np.asarray(gap_lengths, dtype=np.int64)
+    per_scaf = max(1, spec.scaffold_len // spec.gap_spacing - 1)
+    n_scaf = (n_gaps + per_scaf - 1) // per_scaf
+    contig_seqs, contig_off = [], [0]
+    gap_contig = np.zeros(n_gaps, dtype=np.int32); gap_start = np.zeros(n_gaps, dtype=np.int64)
+    truths = []
+    truth_scaf = []                                  # per scaffold: truth array and (gap truth start) list
+    gi = 0
+    for s in range(n_scaf):
+        t = _ALPH[rng.integers(0, 4, size=spec.scaffold_len)]
+        scaf = t.copy()
+        starts = []
+        for k in range(per_scaf):
+            if gi >= n_gaps:
+                break
+            st = (k + 1) * spec.gap_spacing - int(G[gi]) // 2
+            scaf[st:st + G[gi]] = ord("N")
+            gap_contig[gi] = s; gap_start[gi] = st
+            truths.append(t[st:st + G[gi]].copy())
+            starts.append((gi, st))
+            gi += 1
+        contig_seqs.append(scaf); contig_off.append(contig_off[-1] + len(scaf))
+        truth_scaf.append((t, starts))
+    mu, sd = spec.insert_mean, spec.insert_sd
+    u_off, u_pos, u_rev, u_seqs = [0], [], [], []
+    p_off, p_clip, p_match, p_pos, p_ref, p_seqs = [0], [], [], [], [], []
+    meanG = float(np.mean(G + L))
+    for s, (t, starts) in enumerate(truth_scaf):
+        for g, st in starts:
+            g0 = int(G[g]); te = st + g0
+            nU = 0
+            if spec.mode == "unmapped":
+                n = int(round(spec.reads_per_gap_mean * (g0 + L) / meanG))
+                n = max(4, min(n, 3000))
+                left = rng.random(n) < 0.5
+                lo, hi = st - L + 8, max(te - 8, st - L + 9)
+                ms = rng.integers(lo, hi + 1, size=n)
+                isz = np.maximum(np.rint(rng.normal(mu, sd, size=n)).astype(np.int64), 2 * L + 2)
+                # left: forward anchor at p0 = ms + L - isz ; right: reverse anchor at q0 = ms + isz - L
+                p0 = ms + L - isz; q0 = ms + isz - L
+                ok = np.where(left, (p0 >= 0) & (p0 + L <= st), (q0 >= te) & (q0 + L <= len(t)))
+                ms, left, p0, q0 = ms[ok], left[ok], p0[ok], q0[ok]
+                n = len(ms)
+                reads = t[ms[:, None] + np.arange(L)[None, :]]
+                if spec.err > 0:
+                    hit = rng.random(reads.shape) < spec.err
+                    sub = _ALPH[(np.searchsorted(_ALPH, reads) + rng.integers(1, 4, size=reads.shape)) % 4]
+                    reads = np.where(hit, sub, reads)
+                u_pos.append(np.where(left, p0 + 1, q0 + 1).astype(np.int32))
+                u_rev.append(left.astype(np.uint8))
+                u_seqs.append(reads.reshape(-1))
+                nU = n
+            u_off.append(u_off[-1] + nU)
+            # frag-library soft-clipped reads (both modes, RunFigbird.sh:285 then :338)
+            Lp = spec.frag_len if spec.mode == "unmapped" else L
+            npart = spec.partial_cov
+            aligned = rng.integers(6, Lp - 5, size=npart)
+            is_left = rng.random(npart) < 0.5
+            fwd = rng.random(npart) < 0.5
+            rs = np.where(is_left, st - aligned, te - (Lp - aligned))
+            okp = (rs >= 0) & (rs + Lp <= len(t))
+            aligned, is_left, fwd, rs = aligned[okp], is_left[okp], fwd[okp], rs[okp]
+            preads = t[rs[:, None] + np.arange(Lp)[None, :]]
+            if spec.err > 0 and len(rs):
+                hit = rng.random(preads.shape) < spec.err
+                sub = _ALPH[(np.searchsorted(_ALPH, preads) + rng.integers(1, 4, size=preads.shape)) % 4]
+                preads = np.where(hit, sub, preads)
+            pos1 = np.where(is_left, rs + 1, te + 1)
+            clip = np.where(is_left, st - pos1, Lp - aligned)
+            fm, fs = (180.0, 10.0) if spec.mode == "unmapped" else (mu, sd)
+            fisz = np.rint(rng.normal(fm, fs, size=len(rs))).astype(np.int64)
+            has_mate = rng.random(len(rs)) < 0.8
+            mate = np.where(is_left, np.maximum(1, pos1 - (fisz - Lp)), pos1 + (fisz - Lp))
+            mate = np.where(has_mate, mate, -1)
+            p_clip.append(clip.astype(np.int32)); p_pos.append(pos1.astype(np.int32)); p_ref.append(mate.astype(np.int32))
+            p_match.append(np.where(is_left, np.where(fwd, 1, 4), np.where(fwd, 2, 3)).astype(np.int32))
+            p_seqs.append(preads.reshape(-1)); p_off.append(p_off[-1] + len(rs))
+    cat = lambda lst, dt: (np.concatenate(lst).astype(dt) if lst and sum(len(x) for x in lst) else np.zeros(1, dtype=dt))
+    u_seq = cat(u_seqs, np.uint8); p_seq = cat(p_seqs, np.uint8)
+    nu = u_off[-1]; npr = p_off[-1]
+    Lp = spec.frag_len if spec.mode == "unmapped" else L
+    batch = GapBatch(
+        contig_off=np.asarray(contig_off, dtype=np.int64), contig_seq=np.concatenate(contig_seqs),
+        gap_contig=gap_contig, gap_start=gap_start, gap_len=G.astype(np.int32),
+        gap_stat2=np.tile(np.asarray([1, 0, 0], dtype=np.int32), n_gaps), gap_fillflag=np.ones(n_gaps, dtype=np.int32),
+        u_read_off=np.asarray(u_off, dtype=np.int64), u_anchor_pos=cat(u_pos, np.int32), u_is_reverse=cat(u_rev, np.uint8),
+        u_seq_off=(np.arange(nu + 1, dtype=np.int64) * L), u_seq=u_seq,
+        p_read_off=np.asarray(p_off, dtype=np.int64), p_clipped_index=cat(p_clip, np.int32), p_match=cat(p_match, np.int32),
+        p_pos=cat(p_pos, np.int32), p_ref_pos=cat(p_ref, np.int32), p_seq_off=(np.arange(npr + 1, dtype=np.int64) * Lp),
+        p_seq=p_seq, p_qual=np.full(max(len(p_seq), 1), ord("I"), dtype=np.uint8))
+    return batch, truths
+
+
+def bench_model_case(seed: int, spec: BenchSpec, n_pairs: int = 4000) -> Case:
+    """A small gap-free Case whose myout.sam / stat.txt define the run-level model of a bench run."""
+    c = make_case(f"bench_model_{spec.mode}", seed, spec.mode, [(2000, 10)], contig_len=4 * int(spec.insert_mean) + 6000,
+                  read_len=spec.read_len, insert_mean=spec.insert_mean, insert_sd=spec.insert_sd, coverage=1, err=spec.err,
+                  n_model_pairs=n_pairs, partial_len=(spec.frag_len if spec.mode == "unmapped" else spec.read_len))
+    return c
+
+
+def write_batch_subset(batch, gap_ids, model_case: Case, root: str, spec: BenchSpec) -> dict:
+    """Write the post-Preprocess file layout for a subset of a GapBatch (CPU-baseline sample):
+    the selected gaps are renumbered 0..k-1; their scaffolds are written whole."""
+    tmp = os.path.join(root, "tmp") + "/"; gdir = os.path.join(root, "gaps") + "/"
+    os.makedirs(tmp, exist_ok=True); os.makedirs(gdir, exist_ok=True)
+    contigs = sorted(set(int(batch.gap_contig[g]) for g in gap_ids))
+    remap = {c: i for i, c in enumerate(contigs)}
+    scf = os.path.join(root, "scf.fa")
+    with open(scf, "w") as f:
+        for c in contigs:
+            s = batch.contig_seq[batch.contig_off[c]:batch.contig_off[c + 1]].tobytes().decode()
+            f.write(f">{remap[c]}\n")
+            for k in range(0, len(s), 60):
+                f.write(s[k:k + 60] + "\n")
+    # Every N run of a written scaffold must have a gapInfo line (FillGaps.cpp pairs them in file order),
+    # so all gaps of the selected scaffolds are listed; unselected ones get fillflag via empty read files.
+    all_g = [g for g in range(batch.n_gaps) if int(batch.gap_contig[g]) in remap]
+    all_g.sort(key=lambda g: (remap[int(batch.gap_contig[g])], int(batch.gap_start[g])))
+    sel = set(int(g) for g in gap_ids)
+    with open(tmp + "gapInfo.txt", "w") as f1, open(tmp + "stat2.txt", "w") as f2:
+        for g in all_g:
+            f1.write(f"{remap[int(batch.gap_contig[g])]}\t{int(batch.gap_start[g])}\t{int(batch.gap_len[g])}\n")
+            f2.write("1\t0\t0\n")
+    with open(tmp + "stat.txt", "w") as f:
+        f.write(f"{model_case.n_pairs} 0 {model_case.read_len} 5000")
+    with open(tmp + "myout.sam", "w") as f:
+        for ln in model_case.myout:
+            # model pairs live on contig 0 of the model case; point them at contig 0 here (only its length matters)
+            f.write(ln + "\n")
+    L = spec.read_len
+    anchor = "A" * L
+    for k, g in enumerate(all_g):
+        with open(gdir + f"gaps_{k}.sam", "w") as f:
+            if g in sel and spec.mode == "unmapped":
+                for r in range(int(batch.u_read_off[g]), int(batch.u_read_off[g + 1])):
+                    s = batch.u_seq[batch.u_seq_off[r]:batch.u_seq_off[r + 1]]
+                    rev = int(batch.u_is_reverse[r])
+                    mate = (_COMP_LUT[s][::-1] if rev else s).tobytes().decode()
+                    fl1, fl2 = (73, 133) if rev else (89, 165)
+                    q = f"u{k}_{r}"
+                    f.write("\t".join([q, str(fl1), "0", str(int(batch.u_anchor_pos[r])), f"{L}M", "0", anchor, _qual(L), f"MD:Z:{L}", "IH:i:1"]) + "\n")
+                    f.write("\t".join([q, str(fl2), "0", str(int(batch.u_anchor_pos[r])), "*", "0", mate, _qual(len(mate)), f"MD:Z:{L}", "IH:i:1"]) + "\n")
+        with open(gdir + f"partial_gaps_{k}.sam", "w") as f:
+            if g in sel:
+                for r in range(int(batch.p_read_off[g]), int(batch.p_read_off[g + 1])):
+                    s = batch.p_seq[batch.p_seq_off[r]:batch.p_seq_off[r + 1]].tobytes().decode()
+                    f.write("\t".join([s, str(int(batch.p_clipped_index[r])), str(int(batch.p_match[r])), str(int(batch.p_pos[r])),
+                                       "*", str(int(batch.p_ref_pos[r])), _qual(len(s))]) + "\n")
+    return {"scf": scf, "tmp": tmp, "gaps": gdir, "myout": tmp + "myout.sam", "gap_order": all_g}

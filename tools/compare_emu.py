@@ -16,7 +16,12 @@ def run_one(case, base, exe=EMU, verbose=True, trace=False):
         env["FIG_ORACLE_TRACE"] = os.path.join(base, "ora.trace"); env["FIG_ORACLE_TRACE_LEVEL"] = "1"
         env["FIGFILL_TRACE"] = os.path.join(base, "emu.trace")
     t = time.time(); ro = subprocess.run([ORA, "fillgaps"] + synth.fillgaps_argv(case, po), capture_output=True, text=True, env=env); to = time.time() - t
-    t = time.time(); re_ = subprocess.run([exe] + synth.fillgaps_argv(case, pe), capture_output=True, text=True, env=env); te = time.time() - t
+    t = time.time()
+    try:
+        re_ = subprocess.run(["timeout", "-k", "10", str(int(os.environ.get("FIGFILL_TIMEOUT", "300"))), exe] + synth.fillgaps_argv(case, pe), capture_output=True, text=True, env=env)
+    except Exception as e:
+        print("figfill failed to run:", e); return False
+    te = time.time() - t
     ok = ro.returncode == 0 and re_.returncode == 0
     for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
         a = open(po["tmp"] + fn).read() if os.path.exists(po["tmp"] + fn) else None
@@ -39,6 +44,9 @@ if __name__ == "__main__":
         synth.make_case("u_small", 1, "unmapped", [(3000, 30), (6000, 600)], coverage=20),
     ]
     ok = True
-    for c in cases: ok &= run_one(c, os.path.join(base, c.name), trace=True)
+    exe = os.environ.get("FIGFILL_EXE", EMU)
+    for c in cases:
+        ok &= run_one(c, os.path.join(base, c.name), exe=exe, trace=True)
+        if not ok: break
     print(base)
     sys.exit(0 if ok else 1)

@@ -20,7 +20,7 @@ def one(seed):
 if __name__ == "__main__":
     a, b = int(sys.argv[1]), int(sys.argv[2])
     bad = []
-    with ProcessPoolExecutor(max_workers=8) as ex:
+    with ProcessPoolExecutor(max_workers=int(os.environ.get("FIG_WORKERS", "8"))) as ex:
         for seed, ok, mode, gl in ex.map(one, range(a, b)):
             print(seed, "OK" if ok else "MISMATCH", mode, gl, flush=True)
             if not ok: bad.append(seed)
