@@ -19,35 +19,44 @@
 #include "fig_pack.h"
 
 // ------------------------------------------------------------------------------------- kernel
-// LDS carve-up (doubles first so everything stays 8-byte aligned):
-//   P[4*capG] Q[5*capG] (if PQ_LDS)  wbuf[capW] (if W_LDS)  FigState  gs[capG]  rb[FIG_MAX_READLEN+8]
-template <bool PQ_LDS, bool W_LDS>
-__global__ void fig_fill_kernel(FigDevModel M, FigDevBatch B, int capG, int capW, int cls, int q_begin, int q_end) {
-    extern __shared__ double fig_lds[];
-    double *lp = fig_lds;
+// LDS carve-up (doubles first so everything stays 8-byte aligned), LDS_TAB only:
+//   PQ[4][ncolE] (16 B each)  Q4[ncolE]  wbuf[nteams][Wcap]  | FigState  gs[capGl]  rb[FIG_MAX_READLEN+8]
+struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end; };
+
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
     FigEng E;
     E.tid = threadIdx.x; E.nt = blockDim.x;
+    E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
-    E.capG = capG; E.capW = capW; E.flops = 0;
+    E.capG = A.capG; E.flops = 0;
+    E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
-    fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, capW, &E.scr);
-    if (PQ_LDS) { E.P = lp; lp += 4 * (long long)capG; E.Q = lp; lp += 5 * (long long)capG; }
-    else { E.P = E.scr.Pg; E.Q = E.scr.Qg; }
-    if (W_LDS) { E.wbuf = lp; lp += capW; } else E.wbuf = E.scr.wg;
-    E.S = (FigState *)lp;
+    fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &E.scr);
+    long long off = 0;
+    E.pq_lds = LDS_TAB; E.w_lds = LDS_TAB;
+    if (LDS_TAB) {
+        E.off_pq = 0; E.off_q4 = 8 * A.ncolE; E.off_w = 9 * A.ncolE;
+        off = 9LL * A.ncolE + (long long)A.nteams * A.Wcap;
+        E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
+    } else {
+        E.off_pq = E.off_q4 = E.off_w = 0;
+        E.pq = E.scr.pqg; E.q4 = E.scr.q4g; E.wbuf = E.scr.wg;
+    }
+    E.S = (FigState *)(fig_lds + off);
     unsigned char *bp = (unsigned char *)(E.S + 1);
-    E.gs = bp; bp += ((capG + 7) & ~7);
+    E.gs = bp; bp += ((A.capGl + 7) & ~7);
     E.rb = bp;
-    (void)cls;
+    E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
     // persistent loop over the class's slice [q_begin, q_end) of the cost-sorted order
     while (true) {
         if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
         __syncthreads();
-        int qi = q_begin + E.S->bc_i;
+        int qi = A.q_begin + E.S->bc_i;
         __syncthreads();
-        if (qi >= q_end) break;
+        if (qi >= A.q_end) break;
         E.g = &B.gaps[B.order[qi]];
-        fig_fill_gap(E);
+        fig_fill_gap<LDS_TAB>(E);
     }
     // algorithmic flop count: one atomic per lane at exit
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
@@ -76,7 +85,7 @@ struct fig_ctx {
     FigDevBatch db;
     std::vector<FigDevGap> h_gaps;
     std::vector<int32_t> h_order;
-    struct Cls { int capG, capW, nt; bool pq_lds, w_lds; size_t lds; int q_begin, q_end; int blocks; };
+    struct Cls { FigLaunchClass c; int blocks; };
     std::vector<Cls> classes;
     std::vector<DevBuf> bufs;
     int64_t n_gaps = 0, n_ureads = 0, n_preads = 0, str_total = 0;
@@ -190,16 +199,26 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     ctx->h_insd.push_back(0.0);                                       // insertThresholdMax may equal maxInsertSize (:7194)
     ctx->h_qtab.resize(256);
     for (int c = 0; c < 256; c++) { int Q = c - 33; ctx->h_qtab[c] = pow(10, -Q / 10.0); }   // qualityFilter, :1791-1792
-    size_t nd = (size_t)3 * L + ctx->h_insd.size() + 256;
+    // pair tables for scalar loads: kt = {1-e[k], e[k]}, mt = {1-e-ins-del, e[k]}; the reversed copies serve
+    // reverse-strand reads (readIndex = len-1-j, Figbird.cpp:3569-3576) as rev[(L-len)+j]
+    std::vector<double> pairs((size_t)8 * L);
+    for (int k = 0; k < L; k++) {
+        pairs[2 * k] = ctx->h_ome[k]; pairs[2 * k + 1] = ctx->h_e[k];
+        pairs[2 * L + 2 * k] = ctx->h_ome[L - 1 - k]; pairs[2 * L + 2 * k + 1] = ctx->h_e[L - 1 - k];
+        pairs[4 * L + 2 * k] = ctx->h_m3[k]; pairs[4 * L + 2 * k + 1] = ctx->h_e[k];
+        pairs[6 * L + 2 * k] = ctx->h_m3[L - 1 - k]; pairs[6 * L + 2 * k + 1] = ctx->h_e[L - 1 - k];
+    }
+    std::vector<double> all;
+    size_t o_e = 0; all.insert(all.end(), ctx->h_e.begin(), ctx->h_e.end()); while (all.size() % 8) all.push_back(0);
+    size_t o_pairs = all.size(); all.insert(all.end(), pairs.begin(), pairs.end()); while (all.size() % 8) all.push_back(0);
+    size_t o_m3 = all.size(); all.insert(all.end(), ctx->h_m3.begin(), ctx->h_m3.end()); while (all.size() % 8) all.push_back(0);
+    size_t o_insd = all.size(); all.insert(all.end(), ctx->h_insd.begin(), ctx->h_insd.end()); while (all.size() % 8) all.push_back(0);
+    size_t o_q = all.size(); all.insert(all.end(), ctx->h_qtab.begin(), ctx->h_qtab.end());
+    size_t o_ome = all.size(); all.insert(all.end(), ctx->h_ome.begin(), ctx->h_ome.end());
+    size_t nd = all.size();
     if (ctx->d_model_tabs.p) { hipFree(ctx->d_model_tabs.p); ctx->d_model_tabs.p = nullptr; }
     if (hipMalloc(&ctx->d_model_tabs.p, nd * sizeof(double)) != hipSuccess) return FIG_ENOMEM;
     double *d = (double *)ctx->d_model_tabs.p;
-    std::vector<double> all;
-    all.insert(all.end(), ctx->h_e.begin(), ctx->h_e.end());
-    all.insert(all.end(), ctx->h_ome.begin(), ctx->h_ome.end());
-    all.insert(all.end(), ctx->h_m3.begin(), ctx->h_m3.end());
-    all.insert(all.end(), ctx->h_insd.begin(), ctx->h_insd.end());
-    all.insert(all.end(), ctx->h_qtab.begin(), ctx->h_qtab.end());
     if (hipMemcpy(d, all.data(), nd * sizeof(double), hipMemcpyHostToDevice) != hipSuccess) return FIG_EHIP;
     FigDevModel &dm = ctx->dm;
     dm.L = L; dm.Tmin = m->insert_threshold_min; dm.Tmax = m->insert_threshold_max; dm.cutoff = m->gap_prob_cutoff;
@@ -207,7 +226,8 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
     dm.max_insert = m->max_insert_size;
     for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
-    dm.e = d; dm.ome = d + L; dm.m3 = d + 2 * L; dm.insd = d + 3 * L; dm.qtab = d + 3 * L + ctx->h_insd.size();
+    dm.e = d + o_e; dm.ome = d + o_pairs; dm.m3 = d + o_m3; dm.insd = d + o_insd; dm.qtab = d + o_q;
+    dm.ome1 = d + o_ome;
     ctx->have_model = true;
     return FIG_OK;
 }
@@ -235,17 +255,16 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     int max_blocks = 1;
     for (const FigLaunchClass &lc : K.classes) {
         fig_ctx::Cls c;
-        c.capG = lc.capG; c.capW = lc.capW; c.nt = lc.nt; c.pq_lds = lc.pq_lds; c.w_lds = lc.w_lds; c.lds = lc.lds;
-        c.q_begin = lc.q_begin; c.q_end = lc.q_end;
-        int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(c.lds, 1), (size_t)(2048 / c.nt)));
+        c.c = lc;
+        int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(lc.lds, 1), (size_t)(2048 / lc.nt)));
         per_cu = std::min(per_cu, 8);
-        c.blocks = std::min<int>(c.q_end - c.q_begin, ctx->n_cu * per_cu);
+        c.blocks = std::min<int>(lc.q_end - lc.q_begin, ctx->n_cu * per_cu);
         max_blocks = std::max(max_blocks, c.blocks);
         ctx->classes.push_back(c);
     }
-    int capG_s = K.capG, capW_s = K.capW, capR = K.capR, capP = K.capP, capC = K.capC;
+    int capG_s = K.capG, capR = K.capR, capP = K.capP, capC = K.capC;
     int64_t str_total = K.str_total;
-    int64_t stride = fig_scratch_layout(nullptr, capG_s, capR, capP, capC, capW_s, nullptr);
+    int64_t stride = fig_scratch_layout(nullptr, capG_s, capR, capP, capC, K.capW, K.capE, nullptr);
     stride = (stride + 255) & ~255LL;
     std::vector<FigDevGap> &gaps = K.gaps; std::vector<int32_t> &order = K.order;
     std::vector<uint32_t> &packed = K.packed; std::vector<uint8_t> &qual = K.qual, &flank = K.flank;
@@ -268,12 +287,12 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)str_total, &p))) return rc; db.str = (char *)p;
     if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.queue_head = (int32_t *)p;
-    if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.counters = (unsigned long long *)p;
+    if ((rc = dev_alloc(ctx, 256, &p))) return rc; db.counters = (unsigned long long *)p;
     if ((rc = dev_alloc(ctx, (size_t)stride * max_blocks, &p))) return rc; db.scratch = (uint8_t *)p;
     db.scratch_stride = stride;
-    db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC;
+    db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC; db.capW = K.capW; db.capE = K.capE;
     db.n_ureads = ctx->n_ureads;
-    FIG_HIP(hipMemsetAsync(db.counters, 0, 64, ctx->stream));
+    FIG_HIP(hipMemsetAsync(db.counters, 0, 256, ctx->stream));
     hipEventRecord(ctx->ev1, ctx->stream);
     FIG_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -283,12 +302,15 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     return FIG_OK;
 }
 
-template <bool PQ, bool W>
-static hipError_t launch_cls(fig_ctx *ctx, const fig_ctx::Cls &c, int ci) {
-    auto k = fig_fill_kernel<PQ, W>;
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds);
+template <bool LDS_TAB, int NT>
+static hipError_t launch_cls(fig_ctx *ctx, const fig_ctx::Cls &c) {
+    auto k = fig_fill_kernel<LDS_TAB, NT>;
+    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k, dim3(c.blocks), dim3(c.nt), c.lds, ctx->stream, ctx->dm, ctx->db, c.capG, c.capW, ci, c.q_begin, c.q_end);
+    FigKernArgs A;
+    A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
+    A.q_begin = c.c.q_begin; A.q_end = c.c.q_end;
+    hipLaunchKernelGGL(k, dim3(c.blocks), dim3(c.c.nt), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
     return hipGetLastError();
 }
 
@@ -319,7 +341,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         if (talloc((size_t)ng * 8, &p)) { tfree(); return FIG_ENOMEM; } db.draw_len = (int32_t *)p;
         hipMemsetAsync(db.draw_isz, 0, (size_t)nr * 4, ctx->stream);
     }
-    hipMemsetAsync(db.counters, 0, 64, ctx->stream);
+    hipMemsetAsync(db.counters, 0, 256, ctx->stream);
     hipMemsetAsync(db.str, 'N', (size_t)ctx->str_total, ctx->stream);
     hipEventRecord(ctx->ev0, ctx->stream);
     int nl = 0;
@@ -327,9 +349,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         const fig_ctx::Cls &c = ctx->classes[ci];
         hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
         hipError_t e;
-        if (c.pq_lds && c.w_lds) e = launch_cls<true, true>(ctx, c, (int)ci);
-        else if (c.pq_lds) e = launch_cls<true, false>(ctx, c, (int)ci);
-        else e = launch_cls<false, false>(ctx, c, (int)ci);
+        if (c.c.lds_tab) e = c.c.nt == 256 ? launch_cls<true, 256>(ctx, c) : launch_cls<true, 512>(ctx, c);
+        else e = launch_cls<false, 512>(ctx, c);
         if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
         nl++;
     }
@@ -344,8 +365,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipMemcpyAsync(out->filled_len, db.filled_len, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
     hipMemcpyAsync(out->gaptofill, db.gaptofill, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (ctx->str_total) hipMemcpyAsync(hstr.data(), db.str, (size_t)ctx->str_total, hipMemcpyDeviceToHost, ctx->stream);
-    unsigned long long cnt[8] = {0};
-    hipMemcpyAsync(cnt, db.counters, 64, hipMemcpyDeviceToHost, ctx->stream);
+    unsigned long long cnt[32] = {0};
+    hipMemcpyAsync(cnt, db.counters, 256, hipMemcpyDeviceToHost, ctx->stream);
     if (db.dbg_n_cand) {
         hipMemcpyAsync(out->dbg_n_cand, db.dbg_n_cand, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipMemcpyAsync(out->dbg_cand_i, db.dbg_cand_i, (size_t)ng * out->dbg_max_cand * 12, hipMemcpyDeviceToHost, ctx->stream);
@@ -362,6 +383,10 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     if (e != hipSuccess) { ctx->last_hip = (int)e; return FIG_EHIP; }
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->stats.d2h_ms = ms;
+#ifdef FIG_PROF
+    { const char *nm[9] = {"E.phaseA", "E.phaseB", "M.chains", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post"};
+      for (int i = 0; i < 9; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
+#endif
     ctx->stats.place_calls = (int64_t)cnt[0];
     ctx->stats.alg_flops = (double)cnt[1];
     // compact strings

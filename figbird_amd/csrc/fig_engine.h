@@ -58,6 +58,33 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { ato
 
 #define FIG_NOPOS 0x7fffffff
 
+// Optional phase timers (diagnostic build only: -DFIG_PROF).  Lane 0 of each workgroup adds s_memtime
+// deltas to B.counters[8+slot]; never enabled in the shipped library.
+#if defined(FIG_PROF) && !defined(FIG_EMU)
+#define FIG_T0(E) unsigned long long _fig_t = ((E).tid == 0) ? __builtin_readcyclecounter() : 0ULL
+#define FIG_TICK(E, slot) do { if ((E).tid == 0) { unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&(E).B->counters[8 + (slot)], _n - _fig_t); _fig_t = _n; } } while (0)
+#else
+#define FIG_T0(E) do { } while (0)
+#define FIG_TICK(E, slot) do { } while (0)
+#endif
+
+// LDS base of the workgroup.  On the device it is the dynamic shared segment, so pointers formed
+// from it keep address space 3 (ds_read/ds_write); under FIG_EMU it is a host buffer.
+#ifdef FIG_EMU
+static double *fig_lds = nullptr;
+#define FIG_RFL(x) (x)
+typedef const uint32_t *fig_cu32p;
+typedef const double *fig_cdp;
+#else
+extern __shared__ double fig_lds[];
+#define FIG_RFL(x) __builtin_amdgcn_readfirstlane(x)
+// constant address space: uniform loads through these become scalar (s_load) instructions
+typedef const uint32_t __attribute__((address_space(4))) *fig_cu32p;
+typedef const double __attribute__((address_space(4))) *fig_cdp;
+#endif
+
+struct FigPQ { double p, q; };       // probsGap[x][b], errorProbsGap[x][b] of one (column, base)
+
 // ---------------------------------------------------------------------------------------
 // Workgroup-shared scalar state (LDS).  Names follow GapFiller's members (Figbird.cpp:1563-1635).
 struct FigState {
@@ -82,6 +109,10 @@ struct FigState {
     int ibuf[8];
     double lik;                      // return value of placeReads / run
     int ctl[8];
+    // read teams of the unmapped hot path: one read per team, T waves per team
+    int tm_lo[16], tm_hi[16], tm_len[16], tm_tis0[16], tm_dir[16];
+    double wv_v[16]; int wv_o[16];   // per-wave partial arg-max
+    int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics
 };
 
 struct FigTrip { int v[3]; };
@@ -92,6 +123,8 @@ struct FigScr {
     double *ncnt;      // new_counts_gap [5][capG]
     double *tmp;       // qual_gap (partial) / count_pos (seed re-weighting) [5][capG]
     int *pc;           // partial_count_array [4][capG]
+    int *nci;          // integer pile-up of accepted reads [5][capG] (new_counts_gap / finalize's countsGap increments)
+    unsigned char *accf; // [R] accepted flag of the current MLE pass
     int *cov;          // gap_coverage [capG]
     int *region;       // [capG+8]
     unsigned char *cons, *best, *cur, *prev, *orig;   // strings [capG+1]
@@ -111,24 +144,26 @@ struct FigScr {
     int *lcross, *rcross; unsigned char *smflag;      // [P]
     // per candidate
     int *used_read_arr; int *lrmd;                    // [C], [C][2]
-    double *Pg, *Qg;   // global copies of P/Q when they do not fit in LDS
+    FigPQ *pqg; double *q4g;   // extended probability table when it does not fit in LDS
     double *wg;        // global weight buffer when it does not fit in LDS
 };
 
 FIG_HD long long fig_align8(long long x) { return (x + 7) & ~7LL; }
 
 // Carve the slab.  Returns the total size when base == nullptr.
-FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int capP, int capC, int capW, FigScr *s) {
+// capG = scratch columns (max alloc_arg), capE = extended table columns, capW = weight-buffer doubles
+FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int capP, int capC, int capW, int capE, FigScr *s) {
     long long o = 0;
 #define FIG_CARVE(field, type, count) do { if (s) s->field = (type *)(base + o); o = fig_align8(o + (long long)sizeof(type) * (count)); } while (0)
     FIG_CARVE(cnt, double, 5LL * capG);
     FIG_CARVE(ncnt, double, 5LL * capG);
     FIG_CARVE(tmp, double, 5LL * capG);
-    FIG_CARVE(Pg, double, 4LL * capG);
-    FIG_CARVE(Qg, double, 5LL * capG);
+    FIG_CARVE(pqg, FigPQ, 4LL * capE);
+    FIG_CARVE(q4g, double, capE);
     FIG_CARVE(wg, double, capW);
     FIG_CARVE(maxlv, double, capR > capP ? capR : capP);
     FIG_CARVE(pc, int, 4LL * capG);
+    FIG_CARVE(nci, int, 5LL * capG);
     FIG_CARVE(cov, int, capG);
     FIG_CARVE(region, int, 2LL * capG + 16);
     FIG_CARVE(frp, int, 2LL * capR);
@@ -151,6 +186,7 @@ FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int
     FIG_CARVE(colchar, unsigned char, capG + 8);
     FIG_CARVE(mark, unsigned char, capR + 8);
     FIG_CARVE(saved, unsigned char, capR + 8);
+    FIG_CARVE(accf, unsigned char, capR + 8);
     FIG_CARVE(smflag, unsigned char, capP + 8);
 #undef FIG_CARVE
     return o;
@@ -164,11 +200,21 @@ struct FigEng {
     const FigDevGap *g;
     FigState *S;
     FigScr scr;
-    double *P, *Q;                   // [4][capG], [5][capG]  (LDS or scratch)
-    double *wbuf;                    // [capW]
+    // Extended probability table: columns x in [-(L-1), Gmax+L-1) are stored at x+xoff.  pq[b*ncolE + xe]
+    // holds {probsGap, errorProbsGap} of base b<4; q4[xe] = errorProbsGap[..][4].  Flank columns are
+    // materialised from the one-hot tables so the E-step inner loop is branch-free.
+    FigPQ *pq; double *q4;           // generic pointers (LDS or scratch)
+    int ncolE, xoff;
+    int off_pq, off_q4, off_w;       // offsets (in doubles) from fig_lds when the table / weights live in LDS
+    int pq_lds, w_lds;
+    double *wbuf;                    // [nteams][Wcap]
+    int Wcap, nteams;
+    int lane, wave, nw, wsz;         // lane in wave, wave in workgroup, waves per workgroup, lanes per wave
+    const double *kt_fwd, *kt_rev;   // {1-e[k], e[k]} pairs, forward and reversed (index (L-len)+j), for scalar loads
+    const double *mt_fwd, *mt_rev;   // {1-e-ins-del, e[k]} pairs for the MLE pass
     unsigned char *rb;               // staged read codes [FIG_MAX_READLEN + 8]
     unsigned char *gs;               // consensus codes of the gap columns for the MLE pass [capG]
-    int capG, capW;
+    int capG;
     unsigned long long flops;        // per-lane algorithmic flop count
 };
 
@@ -294,7 +340,33 @@ FIG_D int fig_from_code(const FigEng &E, int x, int G, int left, int right) {
 }
 
 // ---------------------------------------------------------------------------------------
-// computeProbsGap(0) + computeErrorProbsGap on the gap columns (A3). All lanes; caller syncs.
+// Accessors of the extended table (generic pointers; the hot loops use the typed LDS form).
+#define FIG_PQ(E, b, x) ((E).pq[(long long)(b) * (E).ncolE + (x) + (E).xoff])
+#define FIG_Q4(E, x) ((E).q4[(x) + (E).xoff])
+
+// Flank columns of the extended table for the current window (G, left, right):
+//   x in [-left, 0)      left-flank base at gapStart+x          -> one-hot / N rows of FP,FQ
+//   x in [G, G+right)    right-flank base at gapStart+G0+(x-G)
+//   anything else        all-zero row (the reference never initialises those rows; placements that start
+//                        left of the window skip them via `index<0`, Figbird.cpp:3578)
+// All lanes; caller syncs.
+FIG_D void fig_build_flank_pq(FigEng &E) {
+    const FigState &S = *E.S;
+    int G = S.G, left = S.left, right = S.right, L1 = E.xoff;
+    int n = 2 * L1;
+    for (int i = E.tid; i < n; i += E.nt) {
+        int x = i < L1 ? i - L1 : G + (i - L1);
+        if (x + E.xoff >= E.ncolE) continue;
+        int c;
+        if (x < 0) c = (-x <= left) ? fig_flank_l(E, -x) : 5;
+        else c = (x - G < right) ? fig_flank_r(E, x - G) : 5;
+        for (int b = 0; b < 4; b++) { FigPQ v; v.p = S.FP[c][b]; v.q = S.FQ[c][b]; FIG_PQ(E, b, x) = v; }
+        FIG_Q4(E, x) = S.FQ[c][4];
+    }
+}
+
+// computeProbsGap(0) + computeErrorProbsGap on the gap columns (A3), Figbird.cpp:2090-2137.
+// All lanes; caller syncs.
 FIG_D void fig_compute_probs(FigEng &E) {
     int n = E.S->ncols, cg = E.capG;
     const double *T = E.M->T;
@@ -307,26 +379,28 @@ FIG_D void fig_compute_probs(FigEng &E) {
             double nq = c4 / 4;
             pr[0] = (c0 + nq) / total; pr[1] = (c1 + nq) / total; pr[2] = (c2 + nq) / total; pr[3] = (c3 + nq) / total;
         } else { pr[0] = pr[1] = pr[2] = pr[3] = .25; }
-        for (int j = 0; j < 4; j++) E.P[j * cg + x] = pr[j];
         for (int j = 0; j < 5; j++) {
             double sum = 0;
             for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
-            E.Q[j * cg + x] = sum;
+            if (j < 4) { FigPQ v; v.p = pr[j]; v.q = sum; FIG_PQ(E, j, x) = v; }
+            else FIG_Q4(E, x) = sum;
         }
     }
+    fig_build_flank_pq(E);
 }
 FIG_D void fig_compute_errprobs_only(FigEng &E) {
-    int n = E.S->ncols, cg = E.capG;
+    int n = E.S->ncols;
     const double *T = E.M->T;
     for (int x = E.tid; x < n; x += E.nt) {
         double pr[4];
-        for (int j = 0; j < 4; j++) pr[j] = E.P[j * cg + x];
+        for (int j = 0; j < 4; j++) pr[j] = FIG_PQ(E, j, x).p;
         for (int j = 0; j < 5; j++) {
             double sum = 0;
             for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
-            E.Q[j * cg + x] = sum;
+            if (j < 4) FIG_PQ(E, j, x).q = sum; else FIG_Q4(E, x) = sum;
         }
     }
+    fig_build_flank_pq(E);
 }
 
 // computeSequence, Figbird.cpp:4417-4508.  All lanes; ends with a barrier.

@@ -55,26 +55,18 @@ FIG_D FigWin fig_window_partial(const FigEng &E, int pos1, int ref_pos, int len,
     return w;
 }
 
-// E-step product of one placement (Figbird.cpp:3142-3167 / :3563-3589), bases j0..j1-1.
+// E-step product of one placement (Figbird.cpp:3142-3167 / :3563-3589), bases j0..j1-1.  Generic
+// (slow) form used by the partial-read path; the unmapped path uses fig_hot_estep().
 FIG_D double fig_estep_chain(FigEng &E, double p, int o, int len, int j0, int j1, int rev, int G, int left, int right) {
-    const double *e = E.M->e, *ome = E.M->ome;
-    const FigState &S = *E.S;
-    int cg = E.capG;
+    const double *e = E.M->e, *ome = E.M->ome1;
+    (void)G; (void)right;
     for (int j = j0; j < j1; j++) {
         int x = o + j;
+        if (x < -left) continue;
         int b = E.rb[j];
         int k = rev ? len - 1 - j : j;
-        double pp, qq;
-        if (x >= 0 && x < G) {
-            qq = E.Q[b * cg + x];
-            pp = b < 4 ? E.P[b * cg + x] : 0.0;
-        } else {
-            int c = fig_col_kind(E, x, G, left, right);
-            if (c < 0) continue;
-            pp = S.FP[c][b]; qq = S.FQ[c][b];
-        }
-        if (b < 4) p *= (pp * ome[k] + e[k] * qq);
-        else p *= (e[k] * qq);
+        if (b < 4) { FigPQ v = FIG_PQ(E, b, x); p *= (v.p * ome[k] + e[k] * v.q); }
+        else p *= (e[k] * FIG_Q4(E, x));
     }
     return p;
 }
@@ -202,7 +194,7 @@ FIG_D void fig_update_partial_prob(FigEng &E, int gaplen) {
         int total = 0, max_index = 0, max_val = -1;
         for (int k = 0; k < 4; k++) { int v = E.scr.pc[k * cg + i]; total += v; if (v > max_val) { max_val = v; max_index = k; } }
         E.scr.colchar[i] = (unsigned char)max_index;
-        for (int k = 0; k < 4; k++) E.P[k * cg + i] = (double)E.scr.pc[k * cg + i] / total;
+        for (int k = 0; k < 4; k++) FIG_PQ(E, k, i).p = (double)E.scr.pc[k * cg + i] / total;
     }
     FIG_SYNC();
     if (E.tid == 0) {
@@ -588,14 +580,18 @@ FIG_D void fig_seed_reweight(FigEng &E) {
     }
 }
 
+#include "fig_engine_hot.h"
+
 // ---------------------------------------------------------------------------------------
 // placeReads, Figbird.cpp:3022-4387.  Returns maxLikelihood in S.lik (after a barrier).
+template <bool LDS>
 FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, int updateflag) {
     FigState &S = *E.S;
     const FigDevModel &M = *E.M;
     int cg = E.capG, G = S.G, left = S.left, right = S.right;
     int nU = E.g->nU, G0 = E.g->G0;
     if (E.tid == 0) fig_atomic_add_u64(&E.B->counters[0], 1ULL);
+    FIG_T0(E);
     for (int x = E.tid; x < S.ncols; x += E.nt) for (int j = 0; j < 5; j++) E.scr.cnt[j * cg + x] = 0;
     for (int r = E.tid; r < nU; r += E.nt) {
         E.scr.maxlv[r] = 0; E.scr.mark[r] = 0; E.scr.frp[r * 2] = -200; E.scr.frp[r * 2 + 1] = 0;
@@ -675,75 +671,22 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
     }
 
     if (M.unmapped == 1) {
-        const FigDevReads &UR = E.B->u;
-        long long ub = E.g->uBase;
-        // ---- E-step (:3530-3689)
-        for (int r = 0; r < nU; r++) {
-            fig_stage_read(E, UR, ub + r);
-            FIG_SYNC();
-            int len = UR.len[ub + r], rev = UR.aux[ub + r];
-            FigWin w = fig_window_unmapped(E, UR.pos[ub + r], len, G, gapoffset);
-            FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
-            for (int o = w.lo + E.tid; o <= w.hi; o += E.nt) {
-                int tis = w.tis0 + w.dir * o;
-                double t = fig_estep_chain(E, M.insd[tis], o, len, 0, len, rev, G, left, right);
-                t = fig_log10(t);
-                if (t > best.v) { best.v = t; best.o = o; }
-                E.wbuf[o - w.lo] = fig_exp(0.5 * t);
-                E.flops += 4ULL * (unsigned long long)len;
-            }
-            best = fig_block_best(E, best);
-            FIG_SYNC();
-            fig_accumulate_columns(E, len, w.lo, w.hi, G);
-            if (E.tid == 0) {
-                if (best.o != FIG_NOPOS) E.scr.maxlv[r] = best.v;
-                else { E.scr.maxlv[r] = 0; S.invalid_count++; }
-            }
-            FIG_SYNC();
-        }
+        // ---- E-step (:3530-3689): fig_engine_hot.h
+        FIG_TICK(E, 4);
+        fig_hot_estep_dispatch<LDS>(E, gapoffset);
+        FIG_TICK(E, 5);
         // ---- consensus + MLE pass (:3694-3914)
         fig_compute_sequence(E, 0, 0);
-        for (int x = E.tid; x < S.ncols; x += E.nt) { E.gs[x] = E.scr.cons[x]; for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = 0; }
+        for (int x = E.tid; x < S.ncols; x += E.nt) E.gs[x] = E.scr.cons[x];
         FIG_SYNC();
-        for (int r = 0; r < nU; r++) {
-            fig_stage_read(E, UR, ub + r);
-            FIG_SYNC();
-            int len = UR.len[ub + r], rev = UR.aux[ub + r];
-            FigWin w = fig_window_unmapped(E, UR.pos[ub + r], len, G, gapoffset);
-            FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
-            for (int o = w.lo + E.tid; o <= w.hi; o += E.nt) {
-                double t = fig_mle_chain(E, o, len, 0, len, rev, G, left, right);
-                if (t > best.v) { best.v = t; best.o = o; }
-                E.flops += (unsigned long long)len;
-            }
-            best = fig_block_best(E, best);
-            int o = best.o == FIG_NOPOS ? -left : best.o;
-            double temp_log_val = -fig_log10(best.v);
-            bool acc = temp_log_val < M.cutoff;
-            if (acc) {
-                for (int j = E.tid; j < len; j += E.nt) {
-                    int x = o + j;
-                    if (x >= 0 && x < G) E.scr.ncnt[E.rb[j] * cg + x] += 1;
-                }
-            }
-            if (E.tid == 0) {
-                if (acc) {
-                    E.scr.maxlv[r] = -temp_log_val;
-                    maxLikelihood += E.scr.maxlv[r];
-                    S.valid_count++;
-                    E.scr.mark[r] = 1;
-                    E.scr.frp[r * 2] = o; E.scr.frp[r * 2 + 1] = len;
-                    if (G == G0) { E.scr.org[r * 2] = o; E.scr.org[r * 2 + 1] = len; }
-                    if (G0 <= 30) {
-                        int val = o + len - G;
-                        if (o < 0 && val > 0) { if (-o > 3 && val > 3) S.ucoverf = 1; }
-                        if (o < 0 && o + len > 0) { if (-o > 3) S.umaxleftf = 1; }
-                        if (o > 0 && o < G && val > 0) { if (val > 3) S.umaxrightf = 1; }
-                    }
-                } else maxLikelihood += -50;
-            }
-            FIG_SYNC();
+        FIG_TICK(E, 6);
+        fig_hot_mle<LDS>(E, gapoffset, 0, G, left, right);
+        FIG_TICK(E, 7);
+        for (int x = E.tid; x < S.ncols; x += E.nt) for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = (double)E.scr.nci[j * cg + x];
+        if (E.tid == 0) {                                  // ordered likelihood sum (:3852-3862)
+            for (int r = 0; r < nU; r++) { if (E.scr.accf[r]) maxLikelihood += E.scr.maxlv[r]; else maxLikelihood += -50; }
         }
+        FIG_SYNC();
         fig_compute_sequence(E, 1, 1);
         // current_str vs previous_str (:3917-3927)
         if (E.tid == 0) { S.ibuf[0] = (S.cons_len == S.prev_len) ? 1 : 0; }
@@ -801,6 +744,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
     }
     if (E.tid == 0) S.lik = maxLikelihood;
     FIG_SYNC();
+    FIG_TICK(E, 8);
 }
 
 // ---------------------------------------------------------------------------------------
@@ -887,6 +831,7 @@ FIG_D int fig_check_update(FigEng &E, int j) {
 
 // ---------------------------------------------------------------------------------------
 // finalize, Figbird.cpp:4929-5659
+template <bool LDS>
 FIG_D void fig_finalize(FigEng &E, int gl) {
     FigState &S = *E.S;
     const FigDevModel &M = *E.M;
@@ -894,7 +839,7 @@ FIG_D void fig_finalize(FigEng &E, int gl) {
     int gapoffset = gl - G0;
     // gapString uses the window of the LAST candidate (left/right as they stand) and bestString (:4978-4996)
     int gsl_left = S.left, gsl_right = S.right;
-    for (int x = E.tid; x < cg; x += E.nt) E.gs[x] = (x < gl) ? (x < S.best_len ? E.scr.best[x] : 4) : 4;
+    for (int x = E.tid; x < gl; x += E.nt) E.gs[x] = x < S.best_len ? E.scr.best[x] : 4;
     for (int i = E.tid; i < S.partial_read_count; i += E.nt) { E.scr.prf[i * 3] = 0; E.scr.prf[i * 3 + 1] = -200; E.scr.prf[i * 3 + 2] = S.partial_read_len; }
     for (int r = E.tid; r < nU; r += E.nt) { E.scr.fin[r * 2] = -200; E.scr.fin[r * 2 + 1] = 0; }
     {
@@ -915,40 +860,19 @@ FIG_D void fig_finalize(FigEng &E, int gl) {
     int draw_on = E.B->draw_pos != nullptr;
 
     if (M.unmapped) {
-        const FigDevReads &UR = E.B->u;
-        long long ub = E.g->uBase;
-        if (E.tid == 0 && E.B->draw_len) E.B->draw_len[(long long)E.g->gapNo * 2] = G;
-        for (int r = 0; r < nU; r++) {
-            fig_stage_read(E, UR, ub + r);
-            FIG_SYNC();
-            int len = UR.len[ub + r], rev = UR.aux[ub + r], pos1 = UR.pos[ub + r];
-            FigWin w = fig_window_unmapped(E, pos1, len, G, gapoffset);
-            FigBest best; best.v = 0; best.o = FIG_NOPOS;
-            for (int o = w.lo + E.tid; o <= w.hi; o += E.nt) {
-                double t = fig_mle_chain(E, o, len, 0, len, rev, gl, gsl_left, gsl_right);
-                if (t > best.v) { best.v = t; best.o = o; }
-                E.flops += (unsigned long long)len;
-            }
-            best = fig_block_best(E, best);
-            int o = best.o == FIG_NOPOS ? -left : best.o;
-            double mp = best.o == FIG_NOPOS ? 0.0 : best.v;
-            bool acc = (-fig_log10(mp) < M.cutoff) && E.scr.saved[r] == 1;
-            if (acc) {
-                for (int j = E.tid; j < len; j += E.nt) { int x = o + j; if (x >= 0 && x < gl) E.scr.cnt[E.rb[j] * cg + x] += 1; }
-            }
-            if (E.tid == 0) {
-                totalCount++;
-                if (acc) {
-                    if (draw_on) { E.B->draw_pos[ub + r] = o; E.B->draw_isz[ub + r] = w.tis0 + w.dir * o; }
-                    E.scr.fin[r * 2] = o; E.scr.fin[r * 2 + 1] = len;
-                    if (o == 0) left_start_zero = 1;
-                    if (o + len == G) right_fin_glen = 1;
-                    if (o < 0 && o + len > 0) { left_right_check[0] = 1; if (-o > unmapped_max_left) unmapped_max_left = -o; }
-                    int val = o + len - G;
-                    if (o < G && val > 0) { left_right_check[1] = 1; if (val > unmapped_max_right) unmapped_max_right = val; }
-                } else discardedCount++;
-            }
-            FIG_SYNC();
+        if (E.tid == 0) { if (E.B->draw_len) E.B->draw_len[(long long)E.g->gapNo * 2] = G; for (int q = 0; q < 8; q++) S.fin_i[q] = 0; }
+        FIG_SYNC();
+        fig_hot_mle<LDS>(E, gapoffset, 1, gl, gsl_left, gsl_right);
+        {
+            int ncl = gl > cg ? cg : gl;
+            for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.cnt[j * cg + x] += (double)E.scr.nci[j * cg + x];
+        }
+        FIG_SYNC();
+        if (E.tid == 0) {
+            left_right_check[0] = S.fin_i[0]; left_right_check[1] = S.fin_i[1];
+            unmapped_max_left = S.fin_i[2]; unmapped_max_right = S.fin_i[3];
+            left_start_zero = S.fin_i[4]; right_fin_glen = S.fin_i[5];
+            totalCount = S.fin_i[6]; discardedCount = S.fin_i[7];
         }
     }
     if (M.partial_flag) {
@@ -1143,6 +1067,7 @@ FIG_D void fig_finalize(FigEng &E, int gl) {
 
 // ---------------------------------------------------------------------------------------
 // run, Figbird.cpp:5913-5965.  Result (valid_count or likelihood) in S.bc_d; S.bc_j = 1 if side_limit < 10.
+template <bool LDS>
 FIG_D void fig_run(FigEng &E, int gaplen, int finalize_flag, int c) {
     FigState &S = *E.S;
     if (E.tid == 0) { S.left = E.M->D; S.right = E.M->D; }
@@ -1154,7 +1079,7 @@ FIG_D void fig_run(FigEng &E, int gaplen, int finalize_flag, int c) {
     for (int p = 0; p < S.num_itr; p++) {
         if (E.tid == 0) { S.valid_count = 0; S.invalid_count = 0; }
         FIG_SYNC();
-        fig_place_reads(E, p, finalize_flag, gaplen - E.g->G0, 0);
+        fig_place_reads<LDS>(E, p, finalize_flag, gaplen - E.g->G0, 0);
         fig_compute_probs(E);
         FIG_SYNC();
         if (E.M->unmapped) { if (S.comp_count >= 5) break; }
@@ -1165,19 +1090,20 @@ FIG_D void fig_run(FigEng &E, int gaplen, int finalize_flag, int c) {
 }
 
 // checkGapReads, Figbird.cpp:6121-6153
+template <bool LDS>
 FIG_D int fig_check_gap_reads(FigEng &E, int org) {
     FigState &S = *E.S;
     if (org < 30) {
         int step = org < 15 ? 10 : 20;
         for (int i = 0; i < 80; i += step) {
-            fig_run(E, i, 1, 1);
+            fig_run<LDS>(E, i, 1, 1);
             if (S.bc_j == 1) return -2;
             if (S.valid_count > 3) return -1;
         }
     } else {
         for (int k = 0; k < 4; k++) {
             int gap = k == 0 ? org / 2 : org * k;
-            fig_run(E, gap, 1, 1);
+            fig_run<LDS>(E, gap, 1, 1);
             if (S.bc_j == 1) return -2;
             if (S.valid_count >= 3) return -1;
         }
@@ -1199,14 +1125,16 @@ FIG_D void fig_dbg_cand(FigEng &E, int gapEstimate, int iters, int valid, double
 }
 
 // run(originalGap,...,1,0); computeSequence(0,0); strcpy(<dst>,concensus)  -- the recurring fallback (:6411-6413 etc.)
+template <bool LDS>
 FIG_D void fig_run_original(FigEng &E, unsigned char *dst, int *dlen) {
-    fig_run(E, E.g->G0, 1, 0);
+    fig_run<LDS>(E, E.g->G0, 1, 0);
     fig_compute_sequence(E, 0, 0);
     fig_copy_str(E, dst, dlen, E.scr.cons, E.S->cons_len);
 }
 
 // ---------------------------------------------------------------------------------------
 // fillGap, Figbird.cpp:6201-6570 (with analyzeGap :6168-6199, findGapLeftRight :2151-2174)
+template <bool LDS>
 FIG_D void fig_fill_gap(FigEng &E) {
     FigState &S = *E.S;
     const FigDevModel &M = *E.M;
@@ -1285,7 +1213,7 @@ FIG_D void fig_fill_gap(FigEng &E) {
     int side_flag = 0, j = 0;
     int less_read_flag = 0;
     FIG_SYNC();
-    if (M.unmapped && G0 <= M.unm_limit && inr) less_read_flag = fig_check_gap_reads(E, G0);
+    if (M.unmapped && G0 <= M.unm_limit && inr) less_read_flag = fig_check_gap_reads<LDS>(E, G0);
     if (less_read_flag == 1) range = 0;
     if (less_read_flag == -2) { side_flag = 1; range = 0; }
     int prev_best = -1, curr_best = 0, prev_u = -1, curr_u = 0, sec_same = 0, sec_same2 = 0;
@@ -1303,7 +1231,7 @@ FIG_D void fig_fill_gap(FigEng &E) {
         for (i = 0; i < S.num_itr; i++) {
             if (E.tid == 0) { S.valid_count = 0; S.invalid_count = 0; }
             FIG_SYNC();
-            fig_place_reads(E, i, finalize_flag, gapEstimate - G0, S.large_gap_flag);
+            fig_place_reads<LDS>(E, i, finalize_flag, gapEstimate - G0, S.large_gap_flag);
             fig_compute_probs(E);
             FIG_SYNC();
             if (M.unmapped) {
@@ -1314,7 +1242,7 @@ FIG_D void fig_fill_gap(FigEng &E) {
         if (M.unmapped && !finalize_flag && inr) {
             if (E.tid == 0) S.valid_count = 0;
             FIG_SYNC();
-            fig_place_reads(E, i, 1, gapEstimate - G0, 0);
+            fig_place_reads<LDS>(E, i, 1, gapEstimate - G0, 0);
         }
         likelihood = S.lik;
         fig_compute_sequence(E, 0, 0);
@@ -1338,7 +1266,7 @@ FIG_D void fig_fill_gap(FigEng &E) {
             if (diff1 <= 0.9) same_count++; else same_count = 0;
             prevlikelihood = likelihood;
             if (same_count == same_thresh && S.G >= G0) break;
-            else if (same_count == same_thresh && S.G < G0) { fig_run_original(E, E.scr.orig, &S.orig_len); break; }
+            else if (same_count == same_thresh && S.G < G0) { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
             if (M.unmapped) {
                 curr_u = valid_count;
                 int du = curr_u - prev_u; if (du < 0) du = -du;
@@ -1346,19 +1274,19 @@ FIG_D void fig_fill_gap(FigEng &E) {
                 else { prev_best = curr_best; sec_same = 0; }
                 if (sec_same >= 2 * same_thresh) {
                     if (S.G >= G0) break;
-                    else { fig_run_original(E, E.scr.orig, &S.orig_len); break; }
+                    else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
                 }
                 if (G0 <= 30) {
                     if (!(S.umaxleftf == 1 || S.umaxrightf == 1 || S.ucoverf == 1)) sec_same2++; else sec_same2 = 0;
                     if (sec_same2 >= 1.5 * same_thresh) {
                         if (S.G >= G0) break;
-                        else { fig_run_original(E, E.scr.orig, &S.orig_len); break; }
+                        else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
                     }
                 }
                 if (S.discont_or_not == 1 && valid_count < 5) stuckCount++; else stuckCount = 0;
                 if (stuckCount > 3 * same_thresh) {
                     if (S.G >= G0) break;
-                    else { fig_run_original(E, E.scr.orig, &S.orig_len); break; }
+                    else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
                 }
             }
         }
@@ -1372,23 +1300,23 @@ FIG_D void fig_fill_gap(FigEng &E) {
     } else if (inr) {
         if (M.unmapped) {
             if (less_read_flag == 1) {
-                fig_run_original(E, E.scr.orig, &S.orig_len);
-                fig_finalize(E, G0);
+                fig_run_original<LDS>(E, E.scr.orig, &S.orig_len);
+                fig_finalize<LDS>(E, G0);
             } else if (side_flag) {
-                fig_run_original(E, E.scr.best, &S.best_len);
-                fig_finalize(E, G0);
+                fig_run_original<LDS>(E, E.scr.best, &S.best_len);
+                fig_finalize<LDS>(E, G0);
             } else {
                 int changed = 0;                         // check_change(used_read_arr, j), :5886-5895
                 if (j != 1) for (int i = 1; i < j && i < E.B->capC; i++) if (E.scr.used_read_arr[0] != E.scr.used_read_arr[i]) { changed = 1; break; }
-                if (changed) fig_finalize(E, maxGapEstimate);
-                else { fig_copy_str(E, E.scr.best, &S.best_len, E.scr.orig, S.orig_len); fig_finalize(E, G0); }
+                if (changed) fig_finalize<LDS>(E, maxGapEstimate);
+                else { fig_copy_str(E, E.scr.best, &S.best_len, E.scr.orig, S.orig_len); fig_finalize<LDS>(E, G0); }
             }
         } else {
             if (maxGapEstimate == 0) {
-                if (E.scr.used_read_arr[0] != 0) fig_finalize(E, maxGapEstimate);
+                if (E.scr.used_read_arr[0] != 0) fig_finalize<LDS>(E, maxGapEstimate);
                 else {
-                    if (maxGapEstimate < G0) fig_run_original(E, E.scr.orig, &S.orig_len);
-                    fig_finalize(E, G0);
+                    if (maxGapEstimate < G0) fig_run_original<LDS>(E, E.scr.orig, &S.orig_len);
+                    fig_finalize<LDS>(E, G0);
                 }
             } else {
                 if (side_flag) {
@@ -1396,7 +1324,7 @@ FIG_D void fig_fill_gap(FigEng &E) {
                     if (E.tid == 0 && idx >= 0 && idx < E.B->capC) { S.left = E.scr.lrmd[idx * 2]; S.right = E.scr.lrmd[idx * 2 + 1]; }
                     FIG_SYNC();
                 }
-                fig_finalize(E, maxGapEstimate);
+                fig_finalize<LDS>(E, maxGapEstimate);
             }
         }
     }

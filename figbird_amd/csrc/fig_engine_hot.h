@@ -1,0 +1,551 @@
+// fig_engine_hot.h -- the unmapped-mode hot loops of placeReads / finalize for gfx950.
+//
+// 99 % of the reference's time is the two triple loops of placeReads (Figbird.cpp:3530-3689 E-step,
+// :3732-3846 MLE pass): for every read, every placement, every base one FP64 factor.  Mapping:
+//
+//   * reads are dealt to TEAMS of T waves (nteams = nw / T reads in flight per workgroup); inside a
+//     team, lanes = placements (stride 64*T);
+//   * everything that is the same for all placements of a read at chain step j -- the read base
+//     b_j (2-bit packed words), {1-e[k], e[k]} -- is wave-uniform and comes in through SCALAR loads
+//     (constant address space -> s_load_dwordx16, s_bfe), so the vector pipe only sees one LDS read
+//     of {P,Q}[b_j][x] (16 B, conflict-free: lane i reads column o_i + j) and four FP64 ops per step:
+//     t1 = P*(1-e); t2 = e*Q; f = t1+t2; p *= f   (no FMA: -ffp-contract=off, as the x86 reference);
+//   * the per-placement weights land in LDS (wbuf[team][placement]); after a workgroup barrier the
+//     lanes switch to COLUMNS and add the weights that cover their column in exactly the reference's
+//     (read, placement) order -- accumulators stay in registers for the whole E-step (no atomics, so
+//     countsGap is bit-identical to the CPU);
+//   * the MLE pass reuses the table area for C[to][x] = errorTypeProbs[from_x][to] (or -1 = match), so a
+//     step is one 8-byte LDS read + two multiplies; arg-max is "first maximum wins".
+#ifndef FIG_ENGINE_HOT_H
+#define FIG_ENGINE_HOT_H
+
+FIG_D FigBest fig_wave_best(const FigEng &E, FigBest x) {
+#ifdef FIG_EMU
+    (void)E;
+    return x;
+#else
+    (void)E;
+    for (int off = 32; off > 0; off >>= 1) {
+        FigBest y;
+        y.v = __shfl_down(x.v, off, 64);
+        y.o = __shfl_down(x.o, off, 64);
+        x = fig_best_merge(x, y);
+    }
+    return x;                         // valid in lane 0
+#endif
+}
+
+// FigEng lives in private memory once the big control functions are not inlined, so the compiler no longer
+// knows that its fields are wave-uniform.  The hot loops re-assert uniformity with readfirstlane, which
+// turns the dependent address arithmetic back into SALU and the table loads into s_load.
+FIG_D int fig_u(int v) { return FIG_RFL(v); }
+template <class T> FIG_D T *fig_uptr(T *p) {
+#ifdef FIG_EMU
+    return p;
+#else
+    unsigned long long v = (unsigned long long)p;
+    unsigned lo = FIG_RFL((unsigned)(v & 0xffffffffu)), hi = FIG_RFL((unsigned)(v >> 32));
+    return (T *)(((unsigned long long)hi << 32) | lo);
+#endif
+}
+FIG_D long long fig_u64(long long w) {
+#ifdef FIG_EMU
+    return w;
+#else
+    unsigned lo = FIG_RFL((unsigned)((unsigned long long)w & 0xffffffffu)), hi = FIG_RFL((unsigned)((unsigned long long)w >> 32));
+    return (long long)(((unsigned long long)hi << 32) | lo);
+#endif
+}
+
+template <bool LDS> FIG_D const FigPQ *fig_pq_ptr(const FigEng &E) { return LDS ? (const FigPQ *)(fig_lds + fig_u(E.off_pq)) : fig_uptr(E.pq); }
+template <bool LDS> FIG_D const double *fig_q4_ptr(const FigEng &E) { return LDS ? (const double *)(fig_lds + fig_u(E.off_q4)) : fig_uptr(E.q4); }
+template <bool LDS> FIG_D double *fig_w_ptr(const FigEng &E) { return LDS ? (double *)(fig_lds + fig_u(E.off_w)) : fig_uptr(E.wbuf); }
+template <bool LDS> FIG_D double *fig_c_ptr(const FigEng &E) { return LDS ? (double *)(fig_lds + fig_u(E.off_pq)) : (double *)fig_uptr(E.pq); }
+
+// base j of a packed read through scalar loads
+FIG_D int fig_sbase(fig_cu32p pk, int nw2, int j) {
+    uint32_t w = pk[j >> 4], m = pk[nw2 + (j >> 5)];
+    return ((m >> (j & 31)) & 1) ? 4 : (int)((w >> ((j & 15) * 2)) & 3);
+}
+
+// E-step product chain of one placement (one lane).  xe0 = o + xoff.
+template <bool LDS>
+FIG_D double fig_hot_chain_e(const FigPQ *PQ, const double *Q4, int ncolE, fig_cu32p pk, int nw2, fig_cdp kt, int len,
+                             int jstart, bool clipped, int xe0, double p) {
+    for (int wi = 0; wi < nw2; wi++) {
+        uint32_t w = pk[wi];
+        uint32_t m = (pk[nw2 + (wi >> 1)] >> ((wi & 1) * 16)) & 0xffffu;
+        int j0 = wi * 16;
+        int nb = len - j0; if (nb > 16) nb = 16;
+        fig_cdp k2 = kt + 2 * j0;
+        const FigPQ *col = PQ + xe0 + j0;
+        if (m == 0 && nb == 16 && !clipped) {
+            // issue the 16 LDS reads of the block first, then run the dependent multiply chain
+            FigPQ v[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) v[jj] = col[(int)((w >> (2 * jj)) & 3) * ncolE + jj];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                double ome = k2[2 * jj], e = k2[2 * jj + 1];
+                p *= (v[jj].p * ome + e * v[jj].q);
+            }
+        } else {
+            for (int jj = 0; jj < nb; jj++) {
+                if (j0 + jj < jstart) continue;
+                double ome = k2[2 * jj], e = k2[2 * jj + 1];
+                if ((m >> jj) & 1) p *= (e * Q4[xe0 + j0 + jj]);
+                else {
+                    int b = (int)((w >> (2 * jj)) & 3);
+                    FigPQ v = col[b * ncolE + jj];
+                    p *= (v.p * ome + e * v.q);
+                }
+            }
+        }
+    }
+    return p;
+}
+
+// Two placements per lane at once (same read => same scalar data): twice the independent work per
+// scalar-table fetch and two independent multiply chains to hide FP64 latency.
+template <bool LDS>
+FIG_D void fig_hot_chain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, int nw2, fig_cdp kt, int len, int xa, int xb, double &pa, double &pb) {
+    for (int wi = 0; wi < nw2; wi++) {
+        uint32_t w = pk[wi];
+        int j0 = wi * 16;
+        int nb = len - j0; if (nb > 16) nb = 16;
+        fig_cdp k2 = kt + 2 * j0;
+        const FigPQ *ca = PQ + xa + j0, *cb = PQ + xb + j0;
+        if (nb == 16) {
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                FigPQ va[8], vb[8];
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) { int q = h * 8 + jj; int r = (int)((w >> (2 * q)) & 3) * ncolE + q; va[jj] = ca[r]; vb[jj] = cb[r]; }
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) {
+                    int q = h * 8 + jj;
+                    double ome = k2[2 * q], e = k2[2 * q + 1];
+                    pa *= (va[jj].p * ome + e * va[jj].q);
+                    pb *= (vb[jj].p * ome + e * vb[jj].q);
+                }
+            }
+        } else {
+            for (int jj = 0; jj < nb; jj++) {
+                double ome = k2[2 * jj], e = k2[2 * jj + 1];
+                int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj;
+                FigPQ va = ca[r], vb = cb[r];
+                pa *= (va.p * ome + e * va.q);
+                pb *= (vb.p * ome + e * vb.q);
+            }
+        }
+    }
+}
+
+template <bool LDS>
+FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, fig_cdp mt, int len, int xa, int xb, double &qa, double &qb) {
+    for (int wi = 0; wi < nw2; wi++) {
+        uint32_t w = pk[wi];
+        int j0 = wi * 16;
+        int nb = len - j0; if (nb > 16) nb = 16;
+        fig_cdp k2 = mt + 2 * j0;
+        const double *ca = C + xa + j0, *cb = C + xb + j0;
+        if (nb == 16) {
+            double va[16], vb[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
+                double fa = e * va[jj], fb = e * vb[jj];
+                qa *= (va[jj] < 0 ? m3 : fa);
+                qb *= (vb[jj] < 0 ? m3 : fb);
+            }
+        } else {
+            for (int jj = 0; jj < nb; jj++) {
+                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
+                int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj;
+                double va = ca[r], vb = cb[r];
+                double fa = e * va, fb = e * vb;
+                qa *= (va < 0 ? m3 : fa);
+                qb *= (vb < 0 ? m3 : fb);
+            }
+        }
+    }
+}
+
+// MLE product chain of one placement.  C[to*ncolE + xe] = -1 when the consensus base equals `to`,
+// else errorTypeProbs[from][to].  mt = {1-e-ins-del, e} pairs.
+template <bool LDS>
+FIG_D double fig_hot_chain_m(const double *C, int ncolE, fig_cu32p pk, int nw2, fig_cdp mt, int len, int xe0) {
+    double q = 1;
+    for (int wi = 0; wi < nw2; wi++) {
+        uint32_t w = pk[wi];
+        uint32_t m = (pk[nw2 + (wi >> 1)] >> ((wi & 1) * 16)) & 0xffffu;
+        int j0 = wi * 16;
+        int nb = len - j0; if (nb > 16) nb = 16;
+        fig_cdp k2 = mt + 2 * j0;
+        const double *col = C + xe0 + j0;
+        if (m == 0 && nb == 16) {
+            double cv[16];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) cv[jj] = col[(int)((w >> (2 * jj)) & 3) * ncolE + jj];
+#pragma unroll
+            for (int jj = 0; jj < 16; jj++) {
+                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
+                double f = e * cv[jj];
+                q *= (cv[jj] < 0 ? m3 : f);
+            }
+        } else {
+            for (int jj = 0; jj < nb; jj++) {
+                int b = ((m >> jj) & 1) ? 4 : (int)((w >> (2 * jj)) & 3);
+                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
+                double c = col[b * ncolE + jj];
+                double f = e * c;
+                q *= (c < 0 ? m3 : f);
+            }
+        }
+    }
+    return q;
+}
+
+// Table of the MLE pass over the extended columns, from the consensus codes E.gs[0..G) and the
+// flanks (gapString of Figbird.cpp:3304-3323 / :4978-4996).  Overlays the {P,Q} table, which every
+// caller rebuilds (computeProbsGap) before the next E-step.  All lanes; ends with a barrier.
+FIG_D void fig_build_mle_table(FigEng &E, int G, int left, int right) {
+    const double *T = E.M->T;
+    double *C = (double *)E.pq;
+    int n = G + 2 * E.xoff;
+    if (n > E.ncolE) n = E.ncolE;
+    for (int i = E.tid; i < n; i += E.nt) {
+        int x = i - E.xoff;
+        int from = fig_from_code(E, x, G, left, right);
+        for (int to = 0; to < 5; to++) C[(long long)to * E.ncolE + i] = (from == to) ? -1.0 : T[from * 5 + to];
+    }
+    FIG_SYNC();
+}
+
+struct FigReadS { int len, rev, pos; long long woff; };
+
+struct FigHotU {                     // wave-uniform copies of what the hot loops need
+    const int32_t *u_len, *u_aux, *u_pos; const int64_t *u_woff; const uint32_t *packed; const double *insd;
+    const double *kt_fwd, *kt_rev, *mt_fwd, *mt_rev;
+    long long ub, gapStart;
+    int G, left, nU, cg, ncolE, xoff, Wcap, nteams, nw, wsz, L, Tmin, Tmax, cutoff, G0, nt;
+};
+FIG_D FigHotU fig_hot_uniforms(const FigEng &E) {
+    FigHotU U;
+    const FigDevBatch *B = fig_uptr(E.B);
+    const FigDevModel *M = fig_uptr(E.M);
+    const FigDevGap *g = fig_uptr(E.g);
+    const FigState *S = E.S;
+    U.u_len = fig_uptr(B->u.len); U.u_aux = fig_uptr(B->u.aux); U.u_pos = fig_uptr(B->u.pos); U.u_woff = fig_uptr(B->u.woff);
+    U.packed = fig_uptr(B->packed); U.insd = fig_uptr(M->insd);
+    U.kt_fwd = fig_uptr(E.kt_fwd); U.kt_rev = fig_uptr(E.kt_rev); U.mt_fwd = fig_uptr(E.mt_fwd); U.mt_rev = fig_uptr(E.mt_rev);
+    U.ub = fig_u64(g->uBase); U.gapStart = fig_u64(g->gapStart);
+    U.G = fig_u(S->G); U.left = fig_u(S->left); U.nU = fig_u(g->nU); U.cg = fig_u(E.capG); U.ncolE = fig_u(E.ncolE); U.xoff = fig_u(E.xoff);
+    U.Wcap = fig_u(E.Wcap); U.nteams = fig_u(E.nteams); U.nw = fig_u(E.nw); U.wsz = fig_u(E.wsz); U.L = fig_u(M->L);
+    U.Tmin = fig_u(M->Tmin); U.Tmax = fig_u(M->Tmax); U.cutoff = fig_u(M->cutoff); U.G0 = fig_u(g->G0); U.nt = fig_u(E.nt);
+    return U;
+}
+FIG_D FigReadS fig_read_scalars(const FigHotU &U, long long idx) {
+    FigReadS r;
+    r.len = fig_u(U.u_len[idx]);
+    r.rev = fig_u(U.u_aux[idx]);
+    r.pos = fig_u(U.u_pos[idx]);
+    r.woff = fig_u64(U.u_woff[idx]);
+    return r;
+}
+FIG_D FigWin fig_window_u(const FigHotU &U, int pos1, int len, int gapoffset) {     // fig_window_unmapped on uniforms
+    FigWin w;
+    int lo = -(len - 1), hi = U.G - 1;
+    if ((long long)pos1 < U.gapStart) {
+        w.tis0 = (int)(U.gapStart - pos1 + len); w.dir = 1;
+        int a = U.Tmin - w.tis0, b = U.Tmax - w.tis0;
+        if (a > lo) lo = a;
+        if (b < hi) hi = b;
+    } else {
+        int p = pos1 + gapoffset;
+        w.tis0 = (int)(p - U.gapStart + len); w.dir = -1;
+        int a = w.tis0 - U.Tmax, b = w.tis0 - U.Tmin;
+        if (a > lo) lo = a;
+        if (b < hi) hi = b;
+    }
+    w.lo = lo; w.hi = hi;
+    return w;
+}
+
+// ---------------------------------------------------------------------------------------
+// E-step over all unmapped reads of the gap (Figbird.cpp:3530-3689).  CPL = columns per lane.
+template <bool LDS, int CPL>
+FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
+    FigState &S = *E.S;
+    const FigHotU U = fig_hot_uniforms(E);
+    const int G = U.G, left = U.left, nU = U.nU, cg = U.cg;
+    const long long ub = U.ub;
+    const FigPQ *PQ = fig_pq_ptr<LDS>(E);
+    const double *Q4 = fig_q4_ptr<LDS>(E);
+    double *W = fig_w_ptr<LDS>(E);
+    const int ncolE = U.ncolE, xoff = U.xoff, Wcap = U.Wcap;
+    int nteams = U.nteams; if (nteams > U.nw) nteams = U.nw;
+    const int T = U.nw / nteams;
+    const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid;
+    const int team = wave / T, wit = wave - team * T;
+    const bool clipped = left < xoff;              // some placements start left of the window (gap near the contig start)
+    // CPL > 0: each lane owns CPL columns and keeps their 5 accumulators in registers for the whole E-step.
+    // CPL == 0: generic fallback (very long gaps, and the one-lane CPU emulation): accumulate in E.scr.cnt.
+    double acc[CPL > 0 ? CPL : 1][5];
+#pragma unroll
+    for (int m = 0; m < (CPL > 0 ? CPL : 1); m++) for (int b = 0; b < 5; b++) acc[m][b] = 0;
+    if (CPL == 0) {                                   // placeReads zeroed countsGap already (:3050-3056)
+        FIG_SYNC();
+    }
+
+    FIG_T0(E);
+    for (int c0 = 0; c0 < nU; c0 += nteams) {
+        // ---- phase A: lanes = placements
+        int r = c0 + team;
+        FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+        if (team < nteams && r < nU) {
+            FigReadS rs = fig_read_scalars(U, ub + r);
+            FigWin w = fig_window_u(U, rs.pos, rs.len, gapoffset);
+            if (wit == 0 && lane == 0) { S.tm_lo[team] = w.lo; S.tm_hi[team] = w.hi; S.tm_len[team] = rs.len; }
+            fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+            int nw2 = (rs.len + 15) >> 4;
+            fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
+            // weight row covers every placement offset o in [-(L-1), G-1] at index o+(L-1); offsets outside the
+            // insert-size window hold 0.0 so that the column pass needs no window test (x + 0.0 == x exactly)
+            double *wrow = W + (long long)team * Wcap + (U.L - 1);
+            for (int i = -(U.L - 1) + wit * U.wsz + lane; i < G; i += T * U.wsz) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
+            unsigned long long nplace = 0;
+            // does the read contain an N?  (then the generic chain handles it)
+            bool hasN = false;
+            { int nwm = (rs.len + 31) >> 5; uint32_t any = 0; for (int q = 0; q < nwm; q++) any |= pk[nw2 + q]; hasN = any != 0; }
+            const int stride = T * U.wsz;
+            int o = w.lo + wit * U.wsz + lane;
+            if (!hasN && !clipped) {
+                for (; o + stride <= w.hi; o += 2 * stride) {
+                    int ob = o + stride;
+                    double pa = U.insd[w.tis0 + w.dir * o], pb = U.insd[w.tis0 + w.dir * ob];
+                    fig_hot_chain_e2<LDS>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    double ta = fig_log10(pa), tb = fig_log10(pb);
+                    if (ta > best.v) { best.v = ta; best.o = o; }
+                    if (tb > best.v) { best.v = tb; best.o = ob; }
+                    wrow[o] = fig_exp(0.5 * ta);
+                    wrow[ob] = fig_exp(0.5 * tb);
+                    nplace += 2;
+                }
+            }
+            for (; o <= w.hi; o += stride) {
+                int tis = w.tis0 + w.dir * o;
+                int jstart = clipped ? (-left - o > 0 ? -left - o : 0) : 0;
+                double p = fig_hot_chain_e<LDS>(PQ, Q4, ncolE, pk, nw2, kt, rs.len, jstart, clipped, o + xoff, U.insd[tis]);
+                double t = fig_log10(p);
+                if (t > best.v) { best.v = t; best.o = o; }
+                wrow[o] = fig_exp(0.5 * t);
+                nplace++;
+            }
+            E.flops += 4ULL * nplace * (unsigned long long)rs.len;
+            best = fig_wave_best(E, best);
+            if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
+        }
+        FIG_SYNC();
+        FIG_TICK(E, 0);
+        // ---- per-read bookkeeping (:3680-3688)
+        if (tid < nteams && c0 + tid < nU) {
+            FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
+            for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[tid * T + k]; y.o = S.wv_o[tid * T + k]; b = fig_best_merge(b, y); }
+            if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + tid] = b.v;
+            else { E.scr.maxlv[c0 + tid] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
+        }
+        // ---- phase B: lanes = gap columns; reads of the chunk in order.  For one read the additions into the
+        // five per-base accumulators of a column are independent chains; each chain walks that base's positions
+        // in descending j (= ascending placement), which is the reference's order (:3603-3611).
+        for (int t = 0; t < nteams && c0 + t < nU; t++) {
+            const int lo = fig_u(S.tm_lo[t]), hi = fig_u(S.tm_hi[t]), len = fig_u(S.tm_len[t]);
+            if (hi < lo) continue;
+            long long woff = fig_u64(U.u_woff[ub + c0 + t]);
+            fig_cu32p pk = (fig_cu32p)(U.packed + woff);
+            const int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5;
+            const double *wrow = W + (long long)t * Wcap + (U.L - 1);
+            if (CPL == 0) {
+                for (int x = tid; x < G; x += U.nt) {
+                    double a[5];
+                    for (int b = 0; b < 5; b++) a[b] = E.scr.cnt[b * cg + x];
+                    for (int jj = len - 1; jj >= 0; jj--) a[fig_sbase(pk, nw2, jj)] += wrow[x - jj];
+                    for (int b = 0; b < 5; b++) E.scr.cnt[b * cg + x] = a[b];
+                }
+                continue;
+            }
+            const uint32_t cw0 = pk[nw2 + nwm], cw1 = pk[nw2 + nwm + 1];
+            const int n0 = (int)(cw0 & 255), n1 = (int)((cw0 >> 8) & 255), n2 = (int)((cw0 >> 16) & 255), n3 = (int)(cw0 >> 24), n4 = (int)(cw1 & 255);
+            typedef const unsigned char __attribute__((address_space(4))) *fig_cu8p_;
+#ifdef FIG_EMU
+            const unsigned char *pl = (const unsigned char *)(pk + nw2 + nwm + 2);
+#else
+            fig_cu8p_ pl = (fig_cu8p_)(pk + nw2 + nwm + 2);
+#endif
+            int nmin = n0 < n1 ? n0 : n1; if (n2 < nmin) nmin = n2; if (n3 < nmin) nmin = n3;
+            const int o1 = n0, o2 = n0 + n1, o3 = n0 + n1 + n2, o4 = n0 + n1 + n2 + n3;
+            const double *wx[CPL > 0 ? CPL : 1];
+#pragma unroll
+            for (int m = 0; m < CPL; m++) { int x = tid + m * U.nt; wx[m] = wrow + (x < G ? x : 0); }
+            for (int k = 0; k < nmin; k++) {
+                const int j0 = pl[k], j1 = pl[o1 + k], j2 = pl[o2 + k], j3 = pl[o3 + k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) {
+                    acc[m][0] += wx[m][-j0]; acc[m][1] += wx[m][-j1]; acc[m][2] += wx[m][-j2]; acc[m][3] += wx[m][-j3];
+                }
+            }
+            for (int k = nmin; k < n0; k++) { const int j = pl[k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) acc[m][0] += wx[m][-j]; }
+            for (int k = nmin; k < n1; k++) { const int j = pl[o1 + k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) acc[m][1] += wx[m][-j]; }
+            for (int k = nmin; k < n2; k++) { const int j = pl[o2 + k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) acc[m][2] += wx[m][-j]; }
+            for (int k = nmin; k < n3; k++) { const int j = pl[o3 + k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) acc[m][3] += wx[m][-j]; }
+            for (int k = 0; k < n4; k++) { const int j = pl[o4 + k];
+#pragma unroll
+                for (int m = 0; m < CPL; m++) acc[m][4] += wx[m][-j]; }
+        }
+        FIG_SYNC();
+        FIG_TICK(E, 1);
+    }
+    if (CPL > 0) {
+#pragma unroll
+        for (int m = 0; m < CPL; m++) {
+            int x = tid + m * U.nt;
+            if (x < G) for (int b = 0; b < 5; b++) E.scr.cnt[b * cg + x] = acc[m][b];
+        }
+    }
+    FIG_SYNC();
+}
+
+template <bool LDS>
+FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
+    int cpl = (E.S->G + E.nt - 1) / E.nt;
+    if (cpl <= 1) fig_hot_estep<LDS, 1>(E, gapoffset);
+    else if (cpl == 2) fig_hot_estep<LDS, 2>(E, gapoffset);
+    else if (cpl == 3) fig_hot_estep<LDS, 3>(E, gapoffset);
+    else if (cpl == 4) fig_hot_estep<LDS, 4>(E, gapoffset);
+    else fig_hot_estep<LDS, 0>(E, gapoffset);
+}
+
+// ---------------------------------------------------------------------------------------
+// MLE pass over all unmapped reads.  mode 0: placeReads (Figbird.cpp:3732-3914); mode 1: finalize
+// (:5018-5192).  `gl` = length of the gap string the products are taken against (== S.G except inside
+// finalize, where the string was cut with the previous window), wl/wr = that window's flank extents.
+// Results: E.scr.accf[r], per-read placement in frp (mode 0) / fin (mode 1), integer pile-up in nci,
+// valid_count / flags; the ordered likelihood sum is done afterwards by the caller.
+template <bool LDS>
+FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int wr) {
+    FigState &S = *E.S;
+    const FigHotU U = fig_hot_uniforms(E);
+    const int G = U.G, left = U.left, nU = U.nU, cg = U.cg, G0 = U.G0;
+    const long long ub = U.ub;
+    const int ncolE = U.ncolE, xoff = U.xoff;
+    int nteams = U.nteams; if (nteams > U.nw) nteams = U.nw;
+    const int T = U.nw / nteams;
+    const int wave = fig_u(E.wave), lane = E.lane;
+    const int team = wave / T, wit = wave - team * T;
+    const int ncl = mode == 0 ? S.ncols : (gl > cg ? cg : gl);
+    for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = 0;
+    fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
+    const double *C = fig_c_ptr<LDS>(E);
+    const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
+    FIG_T0(E);
+    for (int c0 = 0; c0 < nU; c0 += nteams) {
+        int r = c0 + team;
+        bool active = team < nteams && r < nU;
+        FigReadS rs; rs.len = 0; rs.rev = 0; rs.pos = 0; rs.woff = 0;
+        FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
+        if (active) {
+            rs = fig_read_scalars(U, ub + r);
+            w = fig_window_u(U, rs.pos, rs.len, gapoffset);
+            fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+            int nw2 = (rs.len + 15) >> 4;
+            fig_cdp mt = (fig_cdp)(rs.rev ? U.mt_rev + 2 * (U.L - rs.len) : U.mt_fwd);
+            FigBest best; best.v = init; best.o = FIG_NOPOS;
+            unsigned long long nplace = 0;
+            bool hasN = false;
+            { int nwm = (rs.len + 31) >> 5; uint32_t any = 0; for (int q = 0; q < nwm; q++) any |= pk[nw2 + q]; hasN = any != 0; }
+            const int stride = T * U.wsz;
+            int o = w.lo + wit * U.wsz + lane;
+            if (!hasN) {
+                for (; o + stride <= w.hi; o += 2 * stride) {
+                    int ob = o + stride;
+                    double qa = 1, qb = 1;
+                    fig_hot_chain_m2<LDS>(C, ncolE, pk, nw2, mt, rs.len, o + xoff, ob + xoff, qa, qb);
+                    if (qa > best.v) { best.v = qa; best.o = o; }
+                    if (qb > best.v) { best.v = qb; best.o = ob; }
+                    nplace += 2;
+                }
+            }
+            for (; o <= w.hi; o += stride) {
+                double q = fig_hot_chain_m<LDS>(C, ncolE, pk, nw2, mt, rs.len, o + xoff);
+                if (q > best.v) { best.v = q; best.o = o; }
+                nplace++;
+            }
+            E.flops += nplace * (unsigned long long)rs.len;
+            best = fig_wave_best(E, best);
+            if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
+        }
+        FIG_SYNC();
+        FIG_TICK(E, 2);
+        // ---- the first wave of each team finishes its read: accept test + integer pile-up
+        if (active && wit == 0) {
+            FigBest b; b.v = init; b.o = FIG_NOPOS;
+            for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[team * T + k]; y.o = S.wv_o[team * T + k]; b = fig_best_merge(b, y); }
+            int o = b.o == FIG_NOPOS ? -left : b.o;
+            double mp = b.o == FIG_NOPOS ? init : b.v;
+            double temp_log_val = -fig_log10(mp);
+            bool acc = temp_log_val < U.cutoff;
+            if (mode == 1) acc = acc && E.scr.saved[r] == 1;
+            if (acc) {
+                fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+                int nw2 = (rs.len + 15) >> 4;
+                for (int j = lane; j < rs.len; j += U.wsz) {
+                    int x = o + j;
+                    if (x >= 0 && x < gl) fig_atomic_add_i32(&E.scr.nci[fig_sbase(pk, nw2, j) * cg + x], 1);
+                }
+            }
+            if (lane == 0) {
+                E.scr.accf[r] = acc ? 1 : 0;
+                if (mode == 0) {
+                    if (acc) {
+                        E.scr.maxlv[r] = -temp_log_val;
+                        fig_atomic_add_i32(&S.valid_count, 1);
+                        E.scr.mark[r] = 1;
+                        E.scr.frp[r * 2] = o; E.scr.frp[r * 2 + 1] = rs.len;
+                        if (G == G0) { E.scr.org[r * 2] = o; E.scr.org[r * 2 + 1] = rs.len; }
+                        if (G0 <= 30) {
+                            int val = o + rs.len - G;
+                            if (o < 0 && val > 0) { if (-o > 3 && val > 3) fig_atomic_or_i32(&S.ucoverf, 1); }
+                            if (o < 0 && o + rs.len > 0) { if (-o > 3) fig_atomic_or_i32(&S.umaxleftf, 1); }
+                            if (o > 0 && o < G && val > 0) { if (val > 3) fig_atomic_or_i32(&S.umaxrightf, 1); }
+                        }
+                    }
+                } else {
+                    fig_atomic_add_i32(&S.fin_i[6], 1);                                   // totalCount
+                    if (acc) {
+                        if (E.B->draw_pos) { E.B->draw_pos[ub + r] = o; E.B->draw_isz[ub + r] = w.tis0 + w.dir * o; }
+                        E.scr.fin[r * 2] = o; E.scr.fin[r * 2 + 1] = rs.len;
+                        if (o == 0) fig_atomic_or_i32(&S.fin_i[4], 1);                    // left_start_zero
+                        if (o + rs.len == G) fig_atomic_or_i32(&S.fin_i[5], 1);           // right_fin_glen
+                        if (o < 0 && o + rs.len > 0) { fig_atomic_or_i32(&S.fin_i[0], 1); fig_atomic_max_i32(&S.fin_i[2], -o); }
+                        int val = o + rs.len - G;
+                        if (o < G && val > 0) { fig_atomic_or_i32(&S.fin_i[1], 1); fig_atomic_max_i32(&S.fin_i[3], val); }
+                    } else fig_atomic_add_i32(&S.fin_i[7], 1);                            // discardedCount
+                }
+            }
+        }
+        FIG_SYNC();
+        FIG_TICK(E, 3);
+    }
+}
+
+#endif

@@ -39,19 +39,29 @@ static inline int code_of(char c) {
     switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
 }
 
+// Packed read = [2-bit words: ceil(len/16)] [N-mask words: ceil(len/32)] [5 per-base counts, 2 words]
+//               [positions of A, then C, G, T, N bases, each list in DESCENDING order: ceil(len/4) words].
+// The position lists let the column-accumulation pass of the E-step run one branch-free add chain per base.
 static void pack_read(const char *s, int len, std::vector<uint32_t> &out) {
-    int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5;
+    int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5, nwp = (len + 3) >> 2;
     size_t base = out.size();
-    out.resize(base + nw2 + nwm, 0u);
+    out.resize(base + nw2 + nwm + 2 + nwp, 0u);
+    int cnt[5] = {0, 0, 0, 0, 0};
     for (int j = 0; j < len; j++) {
         int c = code_of(s[j]);
         if (c < 4) out[base + (j >> 4)] |= (uint32_t)c << ((j & 15) * 2);
         else out[base + nw2 + (j >> 5)] |= 1u << (j & 31);
+        cnt[c]++;
     }
+    uint8_t *cb = (uint8_t *)&out[base + nw2 + nwm];
+    for (int c = 0; c < 5; c++) cb[c] = (uint8_t)cnt[c];
+    uint8_t *pl = (uint8_t *)&out[base + nw2 + nwm + 2];
+    int k = 0;
+    for (int c = 0; c < 5; c++)
+        for (int j = len - 1; j >= 0; j--) if (code_of(s[j]) == c) pl[k++] = (uint8_t)j;
 }
 
-
-struct FigLaunchClass { int capG, capW, nt; bool pq_lds, w_lds; size_t lds; int q_begin, q_end; };
+struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end; };
 
 struct FigPacked {
     std::vector<FigDevGap> gaps;
@@ -61,7 +71,7 @@ struct FigPacked {
     std::vector<int32_t> u_pos, u_aux, u_len, p_pos, p_aux, p_clip, p_ref, p_len;
     std::vector<int64_t> u_woff, p_woff, p_qoff, str_off;
     std::vector<FigLaunchClass> classes;
-    int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0;
+    int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0, capE = 0;
     int64_t str_total = 0, n_gaps = 0;
     int64_t packed_bytes() const {
         return (int64_t)(packed.size() * 4 + flank.size() + gaps.size() * sizeof(FigDevGap) + qual.size() +
@@ -144,34 +154,49 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
     }
     K.str_total = str_total; K.str_off[ng] = str_total;
     K.capG = (K.capG + 7) & ~7;
-    K.capW = K.capG + FIG_MAX_READLEN + 8;
-    // ---- LDS classes by column capacity; within a class, most expensive gaps first
-    struct ClsDef { int capG, nt; };
-    const ClsDef defs[] = {{384, 256}, {1024, 512}, {1856, 1024}, {1 << 30, 1024}};
+    // ---- launch classes by the longest candidate a gap can reach (LDS columns); within a class the most
+    // expensive gaps come first.  gmax: candidate range (:6237-6238), checkGapReads probes (:6121-6153).
+    std::vector<int> gmax(ng, 8);
+    for (int64_t g = 0; g < ng; g++) {
+        const FigDevGap &d = K.gaps[g];
+        int gm = std::max(d.G0, (int)(d.G0 * d.gpf2));
+        if (m->unmapped_flag && d.G0 <= m->unm_limit) gm = std::max(gm, d.G0 < 30 ? 70 : 3 * d.G0);
+        gmax[g] = std::min(gm, d.alloc_arg);
+    }
+    struct ClsDef { int capGl, nt; };
+    const ClsDef defs[] = {{448, 256}, {1216, 512}, {1 << 30, 512}};
     K.order.clear(); K.classes.clear();
+    const int L1 = m->max_read_length - 1;
     int prevcap = 0;
     for (const ClsDef &cd : defs) {
         std::vector<int32_t> ids;
-        int mx = 8;
+        int mx = 8, mxa = 8;
         for (int64_t g = 0; g < ng; g++)
-            if (K.gaps[g].alloc_arg > prevcap && K.gaps[g].alloc_arg <= cd.capG) { ids.push_back((int32_t)g); mx = std::max(mx, K.gaps[g].alloc_arg); }
-        prevcap = cd.capG;
+            if (gmax[g] > prevcap && gmax[g] <= cd.capGl) { ids.push_back((int32_t)g); mx = std::max(mx, gmax[g]); mxa = std::max(mxa, K.gaps[g].alloc_arg); }
+        prevcap = cd.capGl;
         if (ids.empty()) continue;
         std::stable_sort(ids.begin(), ids.end(), [&](int32_t a, int32_t c) { return cost[a] > cost[c]; });
         FigLaunchClass c;
-        c.capG = (mx + 7) & ~7;
-        c.capW = c.capG + FIG_MAX_READLEN + 8;
+        c.capG = (mxa + 7) & ~7;
+        c.capGl = (mx + 7) & ~7;
+        c.ncolE = (c.capGl + 2 * L1 + 7) & ~7;
+        c.Wcap = (c.capGl + m->max_read_length + 7) & ~7;
         c.nt = cd.nt;
-        size_t fixed = state_bytes + (size_t)((c.capG + 7) & ~7) + FIG_MAX_READLEN + 16;
-        size_t pq = (size_t)9 * c.capG * sizeof(double), wb = (size_t)c.capW * sizeof(double);
-        const size_t LDS_MAX = 160 * 1024 - 512;
-        c.pq_lds = fixed + pq <= LDS_MAX;
-        c.w_lds = fixed + (c.pq_lds ? pq : 0) + wb <= LDS_MAX;
-        c.lds = fixed + (c.pq_lds ? pq : 0) + (c.w_lds ? wb : 0);
+        const size_t LDS_MAX = 160 * 1024 - 1024;
+        size_t fixed = state_bytes + (size_t)c.capGl + FIG_MAX_READLEN + 64;
+        int nw = c.nt / 64;
+        c.lds_tab = false; c.nteams = nw;
+        for (int nt_ = nw; nt_ >= 1; nt_ >>= 1) {
+            size_t need = fixed + sizeof(double) * ((size_t)9 * c.ncolE + (size_t)nt_ * c.Wcap);
+            if (need <= LDS_MAX) { c.lds_tab = true; c.nteams = nt_; c.lds = need; break; }
+        }
+        if (!c.lds_tab) { c.lds = fixed + 64; c.nt = 512; c.nteams = 8; }
         c.q_begin = (int)K.order.size();
         for (int32_t id : ids) { K.gaps[id].cls = (int)K.classes.size(); K.order.push_back(id); }
         c.q_end = (int)K.order.size();
         K.classes.push_back(c);
+        K.capE = std::max(K.capE, c.ncolE);
+        K.capW = std::max(K.capW, c.nteams * c.Wcap);
     }
     return FIG_OK;
 }

@@ -22,7 +22,8 @@ struct FigDevModel {
     int32_t max_insert;
     double T[25];                    // errorTypeProbs[from][to]
     const double *e;                 // errorPosDist[k]
-    const double *ome;               // 1 - errorPosDist[k]
+    const double *ome;               // pair tables: {1-e,e} fwd [2L], rev [2L]; {1-e-ins-del,e} fwd [2L], rev [2L]
+    const double *ome1;              // 1 - errorPosDist[k]
     const double *m3;                // 1 - errorPosDist[k] - inPosDist[k] - delPosDist[k]
     const double *insd;              // insertLengthDistSmoothed[max_insert]
     const double *qtab;              // [256] pow(10, -(c-33)/10.0)   (qualityFilter, Figbird.cpp:1791-1792)
@@ -67,6 +68,7 @@ struct FigDevBatch {
     // scratch
     uint8_t *scratch; int64_t scratch_stride;   // one slab per workgroup
     int32_t capG, capR, capP, capC;  // capacities the slab was carved for (columns, unmapped reads, partial reads, candidates)
+    int32_t capW, capE;              // weight-buffer doubles, extended-table columns
 };
 
 #endif

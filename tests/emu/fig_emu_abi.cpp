@@ -19,7 +19,7 @@ struct fig_ctx {
     bool have_model = false;
     fig_model hm;
     FigDevModel dm;
-    std::vector<double> e, ome, m3, insd, qtab;
+    std::vector<double> e, ome, m3, insd, qtab, pairs;
     bool have_batch = false;
     FigPacked K;
     fig_stats stats;
@@ -55,7 +55,14 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
     dm.max_insert = m->max_insert_size;
     for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
-    dm.e = ctx->e.data(); dm.ome = ctx->ome.data(); dm.m3 = ctx->m3.data(); dm.insd = ctx->insd.data(); dm.qtab = ctx->qtab.data();
+    ctx->pairs.assign((size_t)8 * L, 0.0);
+    for (int k = 0; k < L; k++) {
+        ctx->pairs[2 * k] = ctx->ome[k]; ctx->pairs[2 * k + 1] = ctx->e[k];
+        ctx->pairs[2 * L + 2 * k] = ctx->ome[L - 1 - k]; ctx->pairs[2 * L + 2 * k + 1] = ctx->e[L - 1 - k];
+        ctx->pairs[4 * L + 2 * k] = ctx->m3[k]; ctx->pairs[4 * L + 2 * k + 1] = ctx->e[k];
+        ctx->pairs[6 * L + 2 * k] = ctx->m3[L - 1 - k]; ctx->pairs[6 * L + 2 * k + 1] = ctx->e[L - 1 - k];
+    }
+    dm.e = ctx->e.data(); dm.ome = ctx->pairs.data(); dm.ome1 = ctx->ome.data(); dm.m3 = ctx->m3.data(); dm.insd = ctx->insd.data(); dm.qtab = ctx->qtab.data();
     ctx->have_model = true;
     return FIG_OK;
 }
@@ -90,21 +97,29 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     B.n_ureads = (int64_t)K.u_pos.size();
     int32_t qh = 0; unsigned long long counters[8] = {0};
     B.queue_head = &qh; B.counters = counters;
-    long long stride = fig_scratch_layout(nullptr, K.capG, K.capR, K.capP, K.capC, K.capW, nullptr);
+    long long stride = fig_scratch_layout(nullptr, K.capG, K.capR, K.capP, K.capC, K.capW, K.capE, nullptr);
     std::vector<unsigned char> slab((size_t)stride + 64, 0);
     B.scratch = slab.data(); B.scratch_stride = stride;
-    B.capG = K.capG; B.capR = K.capR; B.capP = K.capP; B.capC = K.capC;
+    B.capG = K.capG; B.capR = K.capR; B.capP = K.capP; B.capC = K.capC; B.capW = K.capW; B.capE = K.capE;
+    const FigDevModel &M = ctx->dm;
     for (const FigLaunchClass &c : K.classes) {
-        std::vector<double> lds((size_t)(9LL * c.capG + c.capW) + (sizeof(FigState) + c.capG + FIG_MAX_READLEN + 64) / 8 + 8, 0.0);
+        // one emulated lane = one wave of width 1; the class's team count is kept so the chunking logic runs
+        int nteams = 1;
+        std::vector<double> lds((size_t)(9LL * c.ncolE + (long long)nteams * c.Wcap) + (sizeof(FigState) + c.capGl + FIG_MAX_READLEN + 64) / 8 + 8, 0.0);
+        fig_lds = lds.data();
         FigEng E;
-        E.tid = 0; E.nt = 1; E.M = &ctx->dm; E.B = &B; E.capG = c.capG; E.capW = c.capW; E.flops = 0;
-        fig_scratch_layout(slab.data(), K.capG, K.capR, K.capP, K.capC, c.capW, &E.scr);
-        double *lp = lds.data();
-        E.P = lp; lp += 4LL * c.capG; E.Q = lp; lp += 5LL * c.capG; E.wbuf = lp; lp += c.capW;
-        E.S = (FigState *)lp;
+        E.tid = 0; E.nt = 1; E.lane = 0; E.wave = 0; E.nw = 1; E.wsz = 1;
+        E.M = &ctx->dm; E.B = &B; E.capG = c.capG; E.flops = 0;
+        E.ncolE = c.ncolE; E.xoff = M.L - 1; E.Wcap = c.Wcap; E.nteams = nteams;
+        fig_scratch_layout(slab.data(), K.capG, K.capR, K.capP, K.capC, K.capW, K.capE, &E.scr);
+        E.pq_lds = 1; E.w_lds = 1;
+        E.off_pq = 0; E.off_q4 = 8 * c.ncolE; E.off_w = 9 * c.ncolE;
+        E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
+        E.S = (FigState *)(fig_lds + 9LL * c.ncolE + (long long)nteams * c.Wcap);
         unsigned char *bp = (unsigned char *)(E.S + 1);
-        E.gs = bp; bp += ((c.capG + 7) & ~7); E.rb = bp;
-        for (int qi = c.q_begin; qi < c.q_end; qi++) { E.g = &K.gaps[K.order[qi]]; fig_fill_gap(E); }
+        E.gs = bp; bp += ((c.capGl + 7) & ~7); E.rb = bp;
+        E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
+        for (int qi = c.q_begin; qi < c.q_end; qi++) { E.g = &K.gaps[K.order[qi]]; fig_fill_gap<true>(E); }
         counters[1] += E.flops;
     }
     ctx->stats.place_calls = (int64_t)counters[0]; ctx->stats.alg_flops = (double)counters[1];

@@ -23,7 +23,7 @@ if __name__ == "__main__":
     spec.reads_per_gap_mean = rpg
     m, mc = model_for(spec)
     print("model", m.Tmin, m.Tmax, m.cutoff, m.stats, flush=True)
-    eng = api.Engine(0)
+    eng = api.Engine(0, lib_path=os.environ.get("FIG_LIB"))
     eng.set_model(m)
     for G in lens:
         gl = np.full(reps, G)
