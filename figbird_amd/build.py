@@ -18,6 +18,7 @@ LIB = os.path.join(LIBDIR, "libfighip.so")
 FIGFILL = os.path.join(BINDIR, "figfill")
 HOSTLIB = os.path.join(LIBDIR, "libfighost.so")
 EMU = os.path.join(ROOT, "tests", "emu", "figfill_emu")
+EMULIB = os.path.join(ROOT, "tests", "emu", "libfigemu.so")   # test-only: C ABI backed by the one-lane emulation
 ORACLE = os.path.join(ROOT, "oracle", "figbird_oracle")
 REFDIR = os.path.join(ROOT, "oracle", "_ref")
 
@@ -44,7 +45,7 @@ def _run(cmd, **kw):
 
 def build_lib(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("fig_abi.hip", "fig_engine.h", "fig_engine_core.h", "fig_types.h", "fig_pack.h")]
+    srcs = [os.path.join(CSRC, f) for f in ("fig_abi.hip", "fig_engine.h", "fig_engine_core.h", "fig_engine_hot.h", "fig_types.h", "fig_pack.h")]
     srcs.append(os.path.join(ROOT, "include", "figbird_hip.h"))
     if force or not _newer(LIB, srcs):
         _run([HIPCC] + HIP_FLAGS + ["-o", LIB, os.path.join(CSRC, "fig_abi.hip")])
@@ -73,9 +74,11 @@ def build_test_infra(force: bool = False) -> None:
             _run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     host = os.path.join(CSRC, "host")
     srcs = [os.path.join(host, "figfill_main.cpp"), os.path.join(host, "fig_host.cpp"), os.path.join(host, "fig_host.h"),
-            os.path.join(ROOT, "tests", "emu", "fig_emu_abi.cpp")] + [os.path.join(CSRC, f) for f in ("fig_engine.h", "fig_engine_core.h", "fig_types.h", "fig_pack.h")]
+            os.path.join(ROOT, "tests", "emu", "fig_emu_abi.cpp")] + [os.path.join(CSRC, f) for f in ("fig_engine.h", "fig_engine_core.h", "fig_engine_hot.h", "fig_types.h", "fig_pack.h")]
     if force or not _newer(EMU, srcs):
         _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", EMU, srcs[0], srcs[1], srcs[3]])
+    if force or not _newer(EMULIB, srcs):
+        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", EMULIB, srcs[3]])
 
 
 def build_all(force: bool = False) -> None:

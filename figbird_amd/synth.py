@@ -618,3 +618,40 @@ def write_batch_subset(batch, gap_ids, model_case: Case, root: str, spec: BenchS
                     f.write("\t".join([s, str(int(batch.p_clipped_index[r])), str(int(batch.p_match[r])), str(int(batch.p_pos[r])),
                                        "*", str(int(batch.p_ref_pos[r])), _qual(len(s))]) + "\n")
     return {"scf": scf, "tmp": tmp, "gaps": gdir, "myout": tmp + "myout.sam", "gap_order": all_g}
+
+
+def subset_batch(batch, gap_ids):
+    """A GapBatch holding only `gap_ids` (in the given order); scaffolds are kept whole (they are shared)."""
+    from .api import GapBatch
+    gap_ids = [int(g) for g in gap_ids]
+
+    def take(off, *arrs):
+        idx = np.concatenate([np.arange(off[g], off[g + 1]) for g in gap_ids]) if gap_ids else np.zeros(0, dtype=np.int64)
+        new_off = np.zeros(len(gap_ids) + 1, dtype=np.int64)
+        new_off[1:] = np.cumsum([off[g + 1] - off[g] for g in gap_ids])
+        return idx.astype(np.int64), new_off, [a[idx] if len(idx) else a[:0] for a in arrs]
+
+    def take_seq(seq_off, seq, ridx):
+        lens = (seq_off[1:] - seq_off[:-1])[ridx] if len(ridx) else np.zeros(0, dtype=np.int64)
+        new_off = np.zeros(len(ridx) + 1, dtype=np.int64)
+        new_off[1:] = np.cumsum(lens)
+        if len(ridx):
+            pieces = [seq[seq_off[r]:seq_off[r + 1]] for r in ridx]
+            new_seq = np.concatenate(pieces)
+        else:
+            new_seq = np.zeros(1, dtype=np.uint8)
+        return new_off, new_seq
+
+    uidx, u_off, (u_pos, u_rev) = take(batch.u_read_off, batch.u_anchor_pos, batch.u_is_reverse)
+    pidx, p_off, (p_clip, p_match, p_pos, p_ref) = take(batch.p_read_off, batch.p_clipped_index, batch.p_match, batch.p_pos, batch.p_ref_pos)
+    u_soff, u_seq = take_seq(batch.u_seq_off, batch.u_seq, uidx)
+    p_soff, p_seq = take_seq(batch.p_seq_off, batch.p_seq, pidx)
+    _, p_qual = take_seq(batch.p_seq_off, batch.p_qual, pidx)
+    pad = lambda a, dt: (a.astype(dt) if len(a) else np.zeros(1, dtype=dt))
+    gi = np.asarray(gap_ids, dtype=np.int64)
+    return GapBatch(contig_off=batch.contig_off, contig_seq=batch.contig_seq,
+                    gap_contig=pad(batch.gap_contig[gi], np.int32), gap_start=pad(batch.gap_start[gi], np.int64), gap_len=pad(batch.gap_len[gi], np.int32),
+                    gap_stat2=pad(batch.gap_stat2.reshape(-1, 3)[gi].reshape(-1), np.int32), gap_fillflag=pad(batch.gap_fillflag[gi], np.int32),
+                    u_read_off=u_off, u_anchor_pos=pad(u_pos, np.int32), u_is_reverse=pad(u_rev, np.uint8), u_seq_off=u_soff, u_seq=u_seq,
+                    p_read_off=p_off, p_clipped_index=pad(p_clip, np.int32), p_match=pad(p_match, np.int32), p_pos=pad(p_pos, np.int32),
+                    p_ref_pos=pad(p_ref, np.int32), p_seq_off=p_soff, p_seq=p_seq, p_qual=p_qual)

@@ -1,0 +1,28 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Build (or reuse) the native artefacts once per session.  On the GPU box everything is prebuilt and
+    travels with the snapshot; here it compiles in well under a minute."""
+    from figbird_amd import build as fbuild
+    need_hip = not os.path.exists(fbuild.LIB)
+    try:
+        if need_hip:
+            fbuild.build_lib()
+        fbuild.build_figfill()
+        fbuild.build_test_infra()
+    except Exception as e:  # pragma: no cover - surfaced by the tests that need the artefact
+        print("build failed:", e)
+    yield

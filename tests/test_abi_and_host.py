@@ -1,0 +1,104 @@
+"""The C-ABI shared library and the host-side mirror (no GPU compute)."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+import util
+from figbird_amd import api, build as fbuild, synth
+
+
+def _declared_functions():
+    hdr = util.read(os.path.join(util.ROOT, "include", "figbird_hip.h"))
+    names = re.findall(r"^\s*(?:int|void|int64_t|const char \*)\s*\*?\s*(fig_[a-z_]+)\s*\(", hdr, flags=re.M)
+    return sorted(set(names))
+
+
+def test_header_declares_the_documented_surface():
+    assert _declared_functions() == sorted(api.EXPORTS)
+
+
+def test_library_exports_every_declared_symbol():
+    assert os.path.exists(fbuild.LIB), "libfighip.so must be built in-tree (python -m figbird_amd.build)"
+    lib = ctypes.CDLL(fbuild.LIB)
+    for fn in _declared_functions():
+        assert hasattr(lib, fn), fn
+    assert lib.fig_version() == 1
+
+
+def test_no_gpu_means_a_loud_failure_not_a_fallback():
+    """Without a HIP device fig_ctx_create must fail (FIG_ENODEV); with one it must succeed.  Never silent CPU."""
+    lib = api.load_library()
+    ctx = ctypes.c_void_p()
+    rc = lib.fig_ctx_create(0, ctypes.byref(ctx))
+    try:
+        import torch
+        have = torch.cuda.is_available()
+    except Exception:
+        have = False
+    if have:
+        assert rc == 0
+        lib.fig_ctx_destroy(ctx)
+    else:
+        assert rc == -2 and not ctx.value
+        with pytest.raises(RuntimeError):
+            api.Engine(0)
+
+
+def test_struct_layouts_match_the_header():
+    # sizes as the C compiler lays them out (x86-64 SysV): checked against a tiny C program
+    import subprocess, tempfile
+    src = '#include <stdio.h>\n#include "figbird_hip.h"\nint main(){printf("%zu %zu %zu %zu\\n",sizeof(fig_model),sizeof(fig_gap_batch),sizeof(fig_gap_results),sizeof(fig_stats));return 0;}\n'
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "t.c"), "w").write(src)
+        subprocess.check_call(["gcc", "-I", os.path.join(util.ROOT, "include"), "-o", os.path.join(d, "t"), os.path.join(d, "t.c")])
+        out = subprocess.check_output([os.path.join(d, "t")]).decode().split()
+    assert [int(x) for x in out] == [ctypes.sizeof(api.FigModel), ctypes.sizeof(api.FigGapBatch), ctypes.sizeof(api.FigGapResults), ctypes.sizeof(api.FigStats)]
+
+
+def test_host_model_equals_oracle_model(tmp_path):
+    """A0 built by the shipped host code (libfighost.so) vs the oracle's MODEL trace line."""
+    root = util.extract_golden("unmapped_mid_err", str(tmp_path))
+    tr = str(tmp_path / "t.trace")
+    assert util.run_oracle_fillgaps(root, trace=tr).returncode == 0
+    _, om = util.parse_trace(tr)
+    m = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
+                             partial_flag=0, unmapped_flag=1, script_itr=1, max_distance=690, read_length=50, neg_overlap=30, partial_len=50)
+    assert (m.cutoff, m.Tmin, m.Tmax) == om[:3]
+    assert m.stats == om[3:]
+    assert len(m.e) == 50 and np.all(m.e > 0) and np.all(m.e < 1)
+    assert abs(m.T.reshape(5, 5).sum(axis=1) - 1).max() < 1e-12
+
+
+def test_case_to_batch_applies_parse_unmapped_orientation():
+    c = synth.make_case("t", 5, "unmapped", [(3000, 30)], coverage=6, n_model_pairs=50)
+    b = synth.case_to_batch(c)
+    g = c.gaps[0]
+    assert b.n_gaps == 1 and int(b.u_read_off[1]) == len(g.unmapped)
+    for k, r in enumerate(g.unmapped):
+        s = b.u_seq[b.u_seq_off[k]:b.u_seq_off[k + 1]].tobytes().decode()
+        if r.anchor_reverse:
+            assert s == r.mate_seq_fastq and b.u_is_reverse[k] == 0
+        else:
+            assert s == synth.revcomp(r.mate_seq_fastq) and b.u_is_reverse[k] == 1
+
+
+def test_emulation_library_through_the_python_api(tmp_path):
+    """api.Engine drives the same ctypes structs whichever library sits behind the ABI."""
+    name = "partial_small"
+    root = util.extract_golden(name, str(tmp_path))
+    m = util.meta(root)
+    a = m["fillgaps_argv"]
+    model = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
+                                 partial_flag=int(a[4]), unmapped_flag=int(a[5]), script_itr=int(a[3]), max_distance=int(a[1]),
+                                 read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
+    case = synth.make_case(name, 2, "partial", [(3000, 30), (6000, 120), (9000, 10)], insert_mean=180, insert_sd=10, coverage=30, n_model_pairs=800)
+    eng = api.Engine(0, lib_path=fbuild.EMULIB)
+    eng.set_model(model)
+    res = eng.fill(synth.case_to_batch(case))
+    eng.close()
+    exp = [ln.split("\t") for ln in util.read(os.path.join(root, "ref", "gapout.txt")).splitlines()]
+    assert [int(e[4]) for e in exp] == list(res.filled_len)
+    assert [e[5] if len(e) > 5 else "" for e in exp] == res.strings

@@ -1,0 +1,42 @@
+"""CPU checks of the PRODUCT's host code and engine control logic without a GPU: figfill's host side
+(file ingest, model, packer, writers) is the shipped code; the per-gap engine (figbird_amd/csrc/fig_engine*.h)
+is compiled for the host as a one-lane emulation (tests/emu, test infrastructure only).  Parity proper --
+the real HIP kernels through the C ABI -- is in test_gpu_parity.py."""
+import os
+
+import pytest
+
+import util
+
+
+@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+def test_emulated_engine_matches_reference_outputs(name, tmp_path):
+    root = util.extract_golden(name, str(tmp_path))
+    r = util.run_figfill(root, util.EMU)
+    assert r.returncode == 0, r.stderr
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+@pytest.mark.parametrize("name", ["unmapped_small", "partial_brackets", "neg_overlap"])
+def test_candidate_planes_match_oracle(name, tmp_path):
+    """likelihood_arr (Figbird.cpp:6390-6391): per candidate gap length the EM iteration count, valid_count and
+    likelihood; same libm on both sides here, so they must agree exactly."""
+    a = util.extract_golden(name, str(tmp_path / "a"))
+    b = util.extract_golden(name, str(tmp_path / "b"))
+    ta, tb = str(tmp_path / "ora.trace"), str(tmp_path / "emu.trace")
+    assert util.run_oracle_fillgaps(a, trace=ta).returncode == 0
+    assert util.run_figfill(b, util.EMU, trace=tb).returncode == 0
+    ca, ma = util.parse_trace(ta)
+    cb, mb = util.parse_trace(tb)
+    assert ma == mb                      # host model (figfill) == oracle model: cutoff, thresholds, mean, SDs
+    assert ca.keys() == cb.keys()
+    for g in ca:
+        assert ca[g] == cb[g], f"gap {g}"
+
+
+@pytest.mark.parametrize("seed", [401, 402, 403, 404, 405, 406, 407, 408])
+def test_emulated_engine_fuzz(seed, tmp_path):
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    assert run_one(mk(seed), str(tmp_path), exe=util.EMU, verbose=False)

@@ -1,0 +1,150 @@
+"""Parity proper: the HIP engine on a real MI355X, called through the C ABI (ctypes -> libfighip.so, and the
+figfill host binary), against (i) the golden vectors from the reference's own binaries, (ii) the oracle on
+fresh seeded inputs, and (iii) at bench sizes, size-independent properties."""
+import os
+
+import numpy as np
+import pytest
+
+import util
+from figbird_amd import api, build as fbuild, synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _loaded_native():
+    maps = open("/proc/self/maps").read()
+    return "libfighip.so" in maps
+
+
+@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+def test_figfill_on_gpu_matches_reference_outputs(name, tmp_path):
+    """figfill (shipped host + libfighip.so) on the reference's own golden outputs: byte-identical files."""
+    root = util.extract_golden(name, str(tmp_path))
+    r = util.run_figfill(root, util.FIGFILL)
+    assert r.returncode == 0, r.stderr
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+def _model_for(root):
+    a = util.meta(root)["fillgaps_argv"]
+    return api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
+                                partial_flag=int(a[4]), unmapped_flag=int(a[5]), script_itr=int(a[3]), max_distance=int(a[1]),
+                                read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
+
+
+@pytest.mark.parametrize("name", ["unmapped_small", "unmapped_mid_err", "partial_brackets", "neg_overlap"])
+def test_c_abi_planes_within_tolerance(name, tmp_path):
+    """Through the C ABI: filled bases and gaptofill exact; per-candidate likelihood (likelihood_arr,
+    Figbird.cpp:6390-6391) within 1e-6 relative of the oracle (device libm vs glibc differ in the last ulp),
+    EM iteration counts and valid_count exact."""
+    from tools.make_golden import CASES
+    root = util.extract_golden(name, str(tmp_path))
+    tr = str(tmp_path / "o.trace")
+    assert util.run_oracle_fillgaps(root, trace=tr).returncode == 0
+    oc, _ = util.parse_trace(tr)
+    kw = dict(CASES[name])
+    case = synth.make_case(name, kw.pop("seed"), kw.pop("mode"), kw.pop("gap_specs"), **kw)
+    eng = api.Engine(0)
+    assert _loaded_native(), "native libfighip.so must be the code that runs"
+    eng.set_model(_model_for(root))
+    res = eng.fill(synth.case_to_batch(case), debug_cand=2048)
+    eng.close()
+    exp = [ln.split("\t") for ln in util.read(os.path.join(root, "ref", "gapout.txt")).splitlines()]
+    assert [int(e[4]) for e in exp] == list(res.filled_len)
+    assert [e[5] if len(e) > 5 else "" for e in exp] == res.strings
+    for g, cands in oc.items():
+        got = res.cand[g]
+        assert len(got) == len(cands), f"gap {g}: candidate count"
+        for (G1, it1, lik1, v1), (G2, it2, v2, lik2) in zip(cands, got):
+            assert (G1, it1, v1) == (G2, it2, v2), f"gap {g} G={G1}"
+            if np.isfinite(lik1):
+                assert abs(lik1 - lik2) <= 1e-6 * max(1.0, abs(lik1)), f"gap {g} G={G1}: {lik1} vs {lik2}"
+            else:
+                assert lik1 == lik2 or (np.isnan(lik1) and np.isnan(lik2))
+
+
+@pytest.mark.parametrize("seed", list(range(500, 524)))
+def test_gpu_fuzz_against_oracle(seed, tmp_path):
+    """Fresh seeded inputs (all findFrac brackets, both modes, errors, N in reads, negative overlaps)."""
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    assert run_one(mk(seed), str(tmp_path), exe=util.FIGFILL, verbose=False)
+
+
+def _bench_engine(spec, seed=7):
+    import tempfile
+    mc = synth.bench_model_case(seed, spec)
+    d = tempfile.mkdtemp(prefix="figmodel_")
+    p = synth.write_case(mc, d)
+    m = api.model_from_files(p["scf"], p["tmp"], p["myout"], partial_flag=1 if spec.mode == "partial" else 0,
+                             unmapped_flag=1 if spec.mode == "unmapped" else 0, script_itr=1, max_distance=spec.max_distance,
+                             read_length=spec.read_len, neg_overlap=30, partial_len=mc.partial_len)
+    eng = api.Engine(0)
+    eng.set_model(m)
+    return eng, mc
+
+
+def test_bench_shape_properties_unmapped():
+    """BASELINE-shaped unmapped batch (2x150 jump library, GAGE-like gap mix): the fill is deterministic
+    (two passes over the resident batch give identical bytes), long gaps keep the reference's conservative N
+    core, and with these error rates essentially every called base equals the truth."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=40.0)
+    eng, _ = _bench_engine(spec)
+    batch, truth = synth.make_bench_batch(123, 192, spec)
+    eng.upload(batch)
+    r1 = eng.fill_resident()
+    r2 = eng.fill_resident()
+    eng.free_batch(); eng.close()
+    assert r1.strings == r2.strings and list(r1.gaptofill) == list(r2.gaptofill)
+    called = wrong = 0
+    for s, t in zip(r1.strings, truth):
+        t = t.tobytes().decode()
+        if len(s) == len(t):
+            called += sum(1 for a in s if a != "N")
+            wrong += sum(1 for a, b in zip(s, t) if a != "N" and a != b)
+    assert called > 0 and wrong <= 0.002 * called, (called, wrong)
+    assert all(set(s) <= set("ACGTN") for s in r1.strings)
+    assert all(0 <= n for n in r1.filled_len)
+
+
+def test_bench_shape_matches_oracle_on_a_sample(tmp_path):
+    """At bench shape the full batch is too costly for the CPU, so a sample of its gaps is written back to
+    files and checked against the oracle byte for byte."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=30.0)
+    eng, mc = _bench_engine(spec)
+    batch, _ = synth.make_bench_batch(321, 64, spec, gap_lengths=np.array(([12, 40, 90, 500] * 16)))
+    res = eng.fill(batch)
+    eng.close()
+    sample = [0, 1, 2, 3, 9, 18]
+    paths = synth.write_batch_subset(batch, sample, mc, str(tmp_path / "cpu"), spec)
+    case_args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
+                 "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
+    r = util.run([util.ORACLE, "fillgaps"] + case_args, str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stderr
+    lines = util.read(paths["tmp"] + "gapout.txt").splitlines()
+    order = paths["gap_order"]
+    for k, g in enumerate(order):
+        if g not in sample:
+            continue
+        f = lines[k].split("\t")
+        assert int(f[4]) == int(res.filled_len[g]), f"gap {g}"
+        assert (f[5] if len(f) > 5 else "") == res.strings[g], f"gap {g}"
+
+
+def test_partial_mode_bench_shape_properties():
+    spec = synth.BenchSpec(mode="partial", read_len=101, insert_mean=180, insert_sd=10, partial_cov=40)
+    eng, _ = _bench_engine(spec)
+    batch, truth = synth.make_bench_batch(77, 512, spec)
+    r1 = eng.fill(batch)
+    r2 = eng.fill(batch)
+    eng.close()
+    assert r1.strings == r2.strings
+    called = wrong = 0
+    for s, t in zip(r1.strings, truth):
+        t = t.tobytes().decode()
+        if len(s) == len(t):
+            called += sum(1 for a in s if a != "N")
+            wrong += sum(1 for a, b in zip(s, t) if a != "N" and a != b)
+    assert called > 0 and wrong <= 0.01 * called, (called, wrong)

@@ -1,0 +1,52 @@
+"""The oracle (CPU restatement, oracle/) against the golden vectors produced by the REFERENCE's own
+binaries (tests/golden/, made by tools/make_golden.py from oracle/_ref).  The reference ships no tests or
+golden files of its own, so these are the pins: byte-identical gapout / gaptofill / draw /
+filledContigs.fa / Ncount.txt in both of the reference's entry points (Figbird.cpp main, FillGaps.cpp main)."""
+import os
+
+import pytest
+
+import util
+
+
+@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+def test_oracle_matches_reference_figbird_main(name, tmp_path):
+    root = util.extract_golden(name, str(tmp_path))
+    r = util.run_oracle_figbird(root)
+    assert r.returncode == 0, r.stderr
+    for fn in ("gapout0.txt", "gaptofill0.txt", "draw0.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+def test_oracle_matches_reference_fillgaps_main(name, tmp_path):
+    root = util.extract_golden(name, str(tmp_path))
+    r = util.run_oracle_fillgaps(root)
+    assert r.returncode == 0, r.stderr
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+def test_golden_covers_the_reference_edge_cases():
+    """negative overlap closes the gap (gapStringLength 0, gaptofill = overlap), N cores stay in long gaps."""
+    import tarfile
+    got = {}
+    for name in util.GOLDEN_CASES:
+        with tarfile.open(os.path.join(util.GOLDEN, name + ".tar.gz")) as t:
+            got[name] = (t.extractfile(f"{name}/ref/gapout0.txt").read().decode(), t.extractfile(f"{name}/ref/gaptofill0.txt").read().decode())
+    out, gtf = got["neg_overlap"]
+    assert gtf.split() == ["0", "14"]
+    assert out.splitlines()[1].split("\t")[3:5] == ["10", "0"]
+    out, _ = got["unmapped_small"]
+    s = out.splitlines()[1].split("\t")[5]
+    assert len(s) == 600 and "N" * 100 in s and s[:50].count("N") == 0
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_FIGBIRD), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [301, 302, 303, 304, 305, 306])
+def test_oracle_matches_live_reference_on_fresh_seeds(seed, tmp_path):
+    """Where the reference binary is available (this container, and the GPU box via the prebuilt oracle/_ref),
+    fuzz the restatement against it on inputs that are not in the committed fixtures."""
+    from tools.fuzz_ref import mk
+    from tools.compare_ref import compare
+    assert compare(mk(seed), str(tmp_path), verbose=False)

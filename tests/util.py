@@ -1,0 +1,75 @@
+"""Shared helpers of the test-suite (test infrastructure)."""
+from __future__ import annotations
+
+import json
+import os
+import subprocess
+import sys
+import tarfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from figbird_amd import build as fbuild  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+ORACLE = fbuild.ORACLE
+EMU = fbuild.EMU
+FIGFILL = fbuild.FIGFILL
+REF_FIGBIRD = os.path.join(fbuild.REFDIR, "Figbird.out")
+
+GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz")) if os.path.isdir(GOLDEN) else []
+
+
+def extract_golden(name: str, dst: str) -> str:
+    with tarfile.open(os.path.join(GOLDEN, name + ".tar.gz")) as t:
+        t.extractall(dst)
+    return os.path.join(dst, name)
+
+
+def meta(root: str) -> dict:
+    with open(os.path.join(root, "meta.json")) as f:
+        return json.load(f)
+
+
+def read(path: str):
+    with open(path) as f:
+        return f.read()
+
+
+def run(cmd, cwd, env=None, timeout=600):
+    e = dict(os.environ)
+    if env:
+        e.update(env)
+    return subprocess.run(cmd, cwd=cwd, capture_output=True, text=True, env=e, timeout=timeout)
+
+
+def run_oracle_figbird(root: str, trace: str | None = None, level: int = 1):
+    """oracle in Figbird.cpp-main mode; writes tmp/gapout0.txt etc."""
+    m = meta(root)
+    with open(os.path.join(root, "tmp", "gaploads.txt"), "w") as f:
+        f.write("".join(f"{g}\t" for g in range(m["n_gaps"])) + "\n")
+    env = {"FIG_ORACLE_TRACE": trace, "FIG_ORACLE_TRACE_LEVEL": str(level)} if trace else None
+    return run([ORACLE, "figbird"] + m["figbird_argv"], root, env)
+
+
+def run_oracle_fillgaps(root: str, trace: str | None = None, level: int = 1):
+    env = {"FIG_ORACLE_TRACE": trace, "FIG_ORACLE_TRACE_LEVEL": str(level)} if trace else None
+    return run([ORACLE, "fillgaps"] + meta(root)["fillgaps_argv"], root, env)
+
+
+def run_figfill(root: str, exe: str, trace: str | None = None):
+    env = {"FIGFILL_TRACE": trace} if trace else None
+    return run([exe] + meta(root)["fillgaps_argv"], root, env)
+
+
+def parse_trace(path: str):
+    """-> {gap: [(gapEstimate, iters, likelihood, valid)]}, model tuple"""
+    cands, model = {}, None
+    for ln in open(path):
+        f = ln.rstrip("\n").split("\t")
+        if f[0] == "CAND":
+            cands.setdefault(int(f[1]), []).append((int(f[2]), int(f[3]), float.fromhex(f[4]), int(f[5])))
+        elif f[0] == "MODEL":
+            model = (int(f[1]), int(f[2]), int(f[3]), float.fromhex(f[4]), float.fromhex(f[5]), float.fromhex(f[6]))
+    return cands, model
