@@ -23,19 +23,18 @@
 //   PQ[4][ncolE] (16 B each)  Q4[ncolE]  wbuf[nteams][Wcap]  | FigState  gs[capGl]  rb[FIG_MAX_READLEN+8]
 struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end; };
 
-template <bool LDS_TAB, int NT>
-__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
-    FigEng E;
+FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
     E.tid = threadIdx.x; E.nt = blockDim.x;
     E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
     E.capG = A.capG; E.flops = 0;
     E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
-    fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &E.scr);
+    fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &work);
+    E.scr = work;
     long long off = 0;
-    E.pq_lds = LDS_TAB; E.w_lds = LDS_TAB;
-    if (LDS_TAB) {
+    E.pq_lds = lds_tab; E.w_lds = lds_tab;
+    if (lds_tab) {
         E.off_pq = 0; E.off_q4 = 8 * A.ncolE; E.off_w = 9 * A.ncolE;
         off = 9LL * A.ncolE + (long long)A.nteams * A.Wcap;
         E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
@@ -48,7 +47,17 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
     E.gs = bp; bp += ((A.capGl + 7) & ~7);
     E.rb = bp;
     E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
-    // persistent loop over the class's slice [q_begin, q_end) of the cost-sorted order
+}
+
+FIG_D void fig_persist_of(const FigDevBatch &B, const FigDevGap &g, FigPersist &P) {
+    fig_persist_layout(B.persist + g.persistOff, g.capGg, g.nU, g.nP, g.rangeCap, g.nslots, sizeof(FigState), &P);
+}
+
+// ---- sequential mode: whole gaps, one workgroup each (FIG_SCHED=seq)
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
+    FigEng E; FigScr work;
+    fig_eng_init(E, M, B, A, LDS_TAB, work);
     while (true) {
         if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
         __syncthreads();
@@ -56,9 +65,99 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
         __syncthreads();
         if (qi >= A.q_end) break;
         E.g = &B.gaps[B.order[qi]];
+        FigPersist P; fig_persist_of(B, *E.g, P);
+        fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
         fig_fill_gap<LDS_TAB>(E);
     }
-    // algorithmic flop count: one atomic per lane at exit
+    if (E.flops) atomicAdd(&B.counters[1], E.flops);
+}
+
+// ---- candidate-parallel mode, kernel 1: setup + analyzeGap + checkGapReads per gap; skipped gaps finish here
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_begin_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
+    FigEng E; FigScr work;
+    fig_eng_init(E, M, B, A, LDS_TAB, work);
+    while (true) {
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        __syncthreads();
+        int qi = A.q_begin + E.S->bc_i;
+        __syncthreads();
+        if (qi >= A.q_end) break;
+        int gi = B.order[qi];
+        E.g = &B.gaps[gi];
+        FigPersist P; fig_persist_of(B, *E.g, P);
+        fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+        fig_gap_begin<LDS_TAB>(E);
+        if (!E.S->L.inr) {                               // not filled (:6227): one pass without EM, then output
+            while (!E.S->L.done) { fig_eval_candidate<LDS_TAB>(E); fig_loop_step(E); }
+            fig_gap_end<LDS_TAB>(E);
+            if (E.tid == 0) { B.gapctl[gi * 4] = 0; }
+        } else {
+            fig_state_save(E, P);
+            if (E.tid == 0) { B.gapctl[gi * 4] = E.S->L.done ? 2 : 1; B.gapctl[gi * 4 + 1] = E.S->L.j; B.gapctl[gi * 4 + 2] = E.S->L.range; }
+        }
+        __syncthreads();
+    }
+    if (E.flops) atomicAdd(&B.counters[1], E.flops);
+}
+
+// ---- kernel 2: speculative candidate evaluations; items = {gap, candidate index j, slot, -}
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_eval_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A, const int4 *items, int n_items) {
+    FigEng E; FigScr work;
+    fig_eng_init(E, M, B, A, LDS_TAB, work);
+    while (true) {
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        __syncthreads();
+        int qi = E.S->bc_i;
+        __syncthreads();
+        if (qi >= n_items) break;
+        int4 it = items[qi];
+        E.g = &B.gaps[it.x];
+        FigPersist P; fig_persist_of(B, *E.g, P);
+        fig_spec_eval<LDS_TAB>(E, work, P, it.y, it.z, E.g->capGg);
+        __syncthreads();
+    }
+    if (E.flops) atomicAdd(&B.counters[1], E.flops);
+}
+
+// ---- kernel 3: replay the bookkeeping of the speculated candidates in order; entries = {gap, n slots, -, -}
+__global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBatch B, const int4 *entries, int n) {
+    if ((int)blockIdx.x >= n) return;
+    FigEng E; FigScr work;
+    memset(&work, 0, sizeof(work));
+    E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
+    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
+    E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.pq_lds = 0; E.w_lds = 0;
+    E.off_pq = E.off_q4 = E.off_w = 0;
+    E.S = (FigState *)fig_lds;
+    int4 en = entries[blockIdx.x];
+    E.g = &B.gaps[en.x];
+    FigPersist P; fig_persist_of(B, *E.g, P);
+    fig_spec_replay(E, work, P, en.y, E.g->capGg);
+    if (E.tid == 0) { B.gapctl[en.x * 4] = E.S->L.done ? 2 : 1; B.gapctl[en.x * 4 + 1] = E.S->L.j; B.gapctl[en.x * 4 + 2] = E.S->L.range; }
+}
+
+// ---- kernel 4: fallbacks + finalize + output for the gaps whose loop is done; list = gap ids
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_end_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A, const int *list, int n) {
+    FigEng E; FigScr work;
+    fig_eng_init(E, M, B, A, LDS_TAB, work);
+    while (true) {
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        __syncthreads();
+        int qi = E.S->bc_i;
+        __syncthreads();
+        if (qi >= n) break;
+        int gi = list[qi];
+        E.g = &B.gaps[gi];
+        FigPersist P; fig_persist_of(B, *E.g, P);
+        fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+        fig_state_load(E, P);
+        fig_gap_end<LDS_TAB>(E);
+        if (E.tid == 0) B.gapctl[gi * 4] = 0;
+        __syncthreads();
+    }
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
 }
 
@@ -90,6 +189,7 @@ struct fig_ctx {
     std::vector<DevBuf> bufs;
     int64_t n_gaps = 0, n_ureads = 0, n_preads = 0, str_total = 0;
     std::vector<int64_t> h_str_off;
+    int nslots = 32; int *d_items = nullptr, *d_entries = nullptr; size_t sched_cap = 0;
     fig_stats stats;
 };
 
@@ -289,6 +389,11 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.queue_head = (int32_t *)p;
     if ((rc = dev_alloc(ctx, 256, &p))) return rc; db.counters = (unsigned long long *)p;
     if ((rc = dev_alloc(ctx, (size_t)stride * max_blocks, &p))) return rc; db.scratch = (uint8_t *)p;
+    if ((rc = dev_alloc(ctx, (size_t)K.persist_total + 256, &p))) return rc; db.persist = (uint8_t *)p;
+    if ((rc = dev_alloc(ctx, (size_t)std::max<int64_t>(ng, 1) * 16, &p))) return rc; db.gapctl = (int32_t *)p;
+    ctx->nslots = K.nslots; ctx->sched_cap = (size_t)std::max<int64_t>(ng, 1) * 4 * (size_t)(K.nslots + 1);
+    if ((rc = dev_alloc(ctx, ctx->sched_cap * 4, &p))) return rc; ctx->d_items = (int *)p;
+    if ((rc = dev_alloc(ctx, ctx->sched_cap * 4, &p))) return rc; ctx->d_entries = (int *)p;
     db.scratch_stride = stride;
     db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC; db.capW = K.capW; db.capE = K.capE;
     db.n_ureads = ctx->n_ureads;
@@ -302,16 +407,106 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     return FIG_OK;
 }
 
-template <bool LDS_TAB, int NT>
-static hipError_t launch_cls(fig_ctx *ctx, const fig_ctx::Cls &c) {
-    auto k = fig_fill_kernel<LDS_TAB, NT>;
-    hipError_t e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
-    if (e != hipSuccess) return e;
+static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     FigKernArgs A;
     A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
     A.q_begin = c.c.q_begin; A.q_end = c.c.q_end;
-    hipLaunchKernelGGL(k, dim3(c.blocks), dim3(c.c.nt), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
+    return A;
+}
+
+// kind: 0 sequential fill, 1 begin, 2 eval (items), 3 end (list)
+template <bool LDS_TAB, int NT>
+static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, int kind, int blocks, const void *list, int n) {
+    FigKernArgs A = kargs_of(c);
+    hipError_t e = hipSuccess;
+    if (kind == 0) {
+        auto k = fig_fill_kernel<LDS_TAB, NT>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
+    } else if (kind == 1) {
+        auto k = fig_begin_kernel<LDS_TAB, NT>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
+    } else if (kind == 2) {
+        auto k = fig_eval_kernel<LDS_TAB, NT>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A, (const int4 *)list, n);
+    } else {
+        auto k = fig_end_kernel<LDS_TAB, NT>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A, (const int *)list, n);
+    }
     return hipGetLastError();
+}
+
+static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, int kind, int blocks, const void *list, int n) {
+    if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, kind, blocks, list, n) : launch_kind<true, 512>(ctx, c, kind, blocks, list, n);
+    return launch_kind<false, 512>(ctx, c, kind, blocks, list, n);
+}
+
+// Candidate-parallel scheduling of one class (see fig_engine_sched.h).  Host-driven rounds: begin -> {eval chunk,
+// replay}* -> end.  Returns the number of kernel launches, or -1 on a HIP error (ctx->last_hip set).
+static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c) {
+    FigDevBatch &db = ctx->db;
+    const int n_cls = c.c.q_end - c.c.q_begin;
+    int nl = 0;
+    hipError_t e;
+    auto fail = [&](hipError_t er) { ctx->last_hip = (int)er; return -1; };
+    hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
+    if ((e = launch_any(ctx, c, 1, c.blocks, nullptr, 0)) != hipSuccess) return fail(e);
+    nl++;
+    std::vector<int32_t> ctl((size_t)ctx->n_gaps * 4);
+    std::vector<int> ids(ctx->h_order.begin() + c.c.q_begin, ctx->h_order.begin() + c.c.q_end);   // cost-sorted
+    std::vector<int> items, entries, endlist;
+    const int slots_cap = ctx->nslots;
+    const int capacity = std::max(1, c.blocks);
+    while (true) {
+        if ((e = hipMemcpyAsync(ctl.data(), db.gapctl, ctl.size() * 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e);
+        int n_active = 0;
+        for (int g : ids) if (ctl[(size_t)g * 4] == 1) n_active++;
+        if (n_active == 0) break;
+        int chunk = (4 * capacity + n_active - 1) / n_active;
+        chunk = std::max(2, std::min(chunk, slots_cap));
+        items.clear(); entries.clear();
+        for (int g : ids) {
+            if (ctl[(size_t)g * 4] != 1) continue;
+            int j = ctl[(size_t)g * 4 + 1], range = ctl[(size_t)g * 4 + 2];
+            int n = std::min(chunk, range - j);
+            if (n <= 0) { n = 0; }
+            entries.push_back(g); entries.push_back(n); entries.push_back(0); entries.push_back(0);
+        }
+        // items ordered slot-major so that the first candidates of every gap are evaluated first
+        for (int k = 0; k < chunk; k++)
+            for (size_t q = 0; q < entries.size(); q += 4)
+                if (k < entries[q + 1]) { int g = entries[q]; items.push_back(g); items.push_back(ctl[(size_t)g * 4 + 1] + k); items.push_back(k); items.push_back(0); }
+        if (ctx->sched_cap < items.size() || ctx->sched_cap < entries.size()) return fail(hipErrorOutOfMemory);
+        int n_items = (int)(items.size() / 4), n_ent = (int)(entries.size() / 4);
+        if (n_items > 0) {
+            if ((e = hipMemcpyAsync(ctx->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+            hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
+            if ((e = launch_any(ctx, c, 2, std::min(capacity, n_items), ctx->d_items, n_items)) != hipSuccess) return fail(e);
+            nl++;
+        }
+        if ((e = hipMemcpyAsync(ctx->d_entries, entries.data(), entries.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(fig_replay_kernel, dim3(n_ent), dim3(64), sizeof(FigState) + 64, ctx->stream, ctx->dm, ctx->db, (const int4 *)ctx->d_entries, n_ent);
+        if ((e = hipGetLastError()) != hipSuccess) return fail(e);
+        nl++;
+    }
+    endlist.clear();
+    for (int g : ids) if (ctl[(size_t)g * 4] == 2) endlist.push_back(g);
+    if (!endlist.empty()) {
+        if ((e = hipMemcpyAsync(ctx->d_items, endlist.data(), endlist.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
+        hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
+        if ((e = launch_any(ctx, c, 3, std::min(capacity, (int)endlist.size()), ctx->d_items, (int)endlist.size())) != hipSuccess) return fail(e);
+        nl++;
+    }
+    (void)n_cls;
+    return nl;
 }
 
 extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
@@ -345,14 +540,21 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipMemsetAsync(db.str, 'N', (size_t)ctx->str_total, ctx->stream);
     hipEventRecord(ctx->ev0, ctx->stream);
     int nl = 0;
+    const char *sched = getenv("FIG_SCHED");
+    const bool seq = sched && strcmp(sched, "seq") == 0;
+    hipMemsetAsync(db.gapctl, 0, (size_t)std::max<int64_t>(ng, 1) * 16, ctx->stream);
     for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
         const fig_ctx::Cls &c = ctx->classes[ci];
-        hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
-        hipError_t e;
-        if (c.c.lds_tab) e = c.c.nt == 256 ? launch_cls<true, 256>(ctx, c) : launch_cls<true, 512>(ctx, c);
-        else e = launch_cls<false, 512>(ctx, c);
-        if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
-        nl++;
+        if (seq) {
+            hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
+            hipError_t e = launch_any(ctx, c, 0, c.blocks, nullptr, 0);
+            if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
+            nl++;
+        } else {
+            int r = run_class_parallel(ctx, c);
+            if (r < 0) { tfree(); return FIG_EHIP; }
+            nl += r;
+        }
     }
     hipEventRecord(ctx->ev1, ctx->stream);
     hipError_t e = hipStreamSynchronize(ctx->stream);

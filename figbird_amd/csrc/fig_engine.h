@@ -85,6 +85,21 @@ typedef const double __attribute__((address_space(4))) *fig_cdp;
 
 struct FigPQ { double p, q; };       // probsGap[x][b], errorProbsGap[x][b] of one (column, base)
 
+// Loop-carried variables of fillGap's candidate-length loop (Figbird.cpp:6237-6296), kept in memory so the
+// loop can be cut into pieces: begin (setup + checkGapReads), per-candidate evaluation, per-candidate
+// bookkeeping ("step"), end (fallbacks + finalize).  Sequential mode runs the pieces back to back in one
+// workgroup; candidate-parallel mode evaluates several candidates of a gap in different workgroups and
+// replays the bookkeeping in order.
+struct FigLoop {
+    int inr, range, gapMin, j, gapEstimate, maxGapEstimate, finalize_flag;
+    int fill_or_not, same_count, same_thresh, stuckCount, side_flag, less_read_flag;
+    int prev_best, curr_best, prev_u, curr_u, sec_same, sec_same2;
+    int done, need_orig;
+    // result of the last evaluated candidate (what the bookkeeping step consumes)
+    int ev_iters, ev_side_break, ev_fill;
+    double maxLikelihood, secondMaxLikelihood, prevlikelihood, likelihood;
+};
+
 // ---------------------------------------------------------------------------------------
 // Workgroup-shared scalar state (LDS).  Names follow GapFiller's members (Figbird.cpp:1563-1635).
 struct FigState {
@@ -113,9 +128,14 @@ struct FigState {
     int tm_lo[16], tm_hi[16], tm_len[16], tm_tis0[16], tm_dir[16];
     double wv_v[16]; int wv_o[16];   // per-wave partial arg-max
     int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics
+    FigLoop L;
+    // useful-work counters of this gap (speculative candidates that are discarded never reach them)
+    unsigned long long flops_useful; int n_place, pad_np;
 };
 
 struct FigTrip { int v[3]; };
+
+
 
 // Per-workgroup scratch slab (HBM, L2-resident while the gap is being worked on).
 struct FigScr {

@@ -590,7 +590,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
     const FigDevModel &M = *E.M;
     int cg = E.capG, G = S.G, left = S.left, right = S.right;
     int nU = E.g->nU, G0 = E.g->G0;
-    if (E.tid == 0) fig_atomic_add_u64(&E.B->counters[0], 1ULL);
+    if (E.tid == 0) S.n_place++;
     FIG_T0(E);
     for (int x = E.tid; x < S.ncols; x += E.nt) for (int j = 0; j < 5; j++) E.scr.cnt[j * cg + x] = 0;
     for (int r = E.tid; r < nU; r += E.nt) {
@@ -842,6 +842,9 @@ FIG_D void fig_finalize(FigEng &E, int gl) {
     for (int x = E.tid; x < gl; x += E.nt) E.gs[x] = x < S.best_len ? E.scr.best[x] : 4;
     for (int i = E.tid; i < S.partial_read_count; i += E.nt) { E.scr.prf[i * 3] = 0; E.scr.prf[i * 3 + 1] = -200; E.scr.prf[i * 3 + 2] = S.partial_read_len; }
     for (int r = E.tid; r < nU; r += E.nt) { E.scr.fin[r * 2] = -200; E.scr.fin[r * 2 + 1] = 0; }
+    // qual_gap is all zero here in the reference too (initialize() cleared it and only finalize adds to it); clear it
+    // explicitly because in candidate-parallel mode this workgroup's scratch may never have seen this gap's initialize()
+    if (M.partial_flag) for (int x = E.tid; x < cg; x += E.nt) for (int j = 0; j < 5; j++) E.scr.tmp[j * cg + x] = 0;
     {
         long long end_lim = (long long)E.g->alloc_arg;                 // columns relative to left_maxDistance
         long long lim2 = S.end_pos_max - S.left;
@@ -1132,212 +1135,4 @@ FIG_D void fig_run_original(FigEng &E, unsigned char *dst, int *dlen) {
     fig_copy_str(E, dst, dlen, E.scr.cons, E.S->cons_len);
 }
 
-// ---------------------------------------------------------------------------------------
-// fillGap, Figbird.cpp:6201-6570 (with analyzeGap :6168-6199, findGapLeftRight :2151-2174)
-template <bool LDS>
-FIG_D void fig_fill_gap(FigEng &E) {
-    FigState &S = *E.S;
-    const FigDevModel &M = *E.M;
-    const FigDevGap &g = *E.g;
-    int G0 = g.G0, nU = g.nU;
-    int cg = E.capG;
-    // ---- allocate / per-gap reset (:1638-1778, :7342-7343)
-    if (E.tid == 0) {
-        S.left = M.D; S.right = M.D; S.side_limit = 30; S.end_pos_max = 0;
-        S.valid_count = S.invalid_count = 0;
-        S.partial_read_count = M.partial_flag == 1 ? g.nP : 0;       // r_count2 (findcount_file(...,1)) in partial mode
-        S.region_perct = 0; S.region_perct_max = 0;
-        S.partial_read_len = M.partial_len;
-        S.rep_flag = 0; S.one_side_repeat_flag = 0; S.large_gap_flag = g.lgf; S.comp_count = 0;
-        S.left_max = 0; S.right_min = 0; S.discont_or_not = 0;
-        S.psr_temp[0] = S.psr_temp[1] = S.psr_final[0] = S.psr_final[1] = -1;
-        S.umaxleftf = S.umaxrightf = S.ucoverf = 0;
-        S.num_itr = 0; S.overlap_threshold = 0; S.gaptofill = 0;
-        S.gl_len = S.gr_len = S.pl_len = S.pr_len = 0;
-        S.cons_len = 1; E.scr.cons[0] = 4;
-        S.best_len = S.cur_len = S.prev_len = S.orig_len = 0;
-        fig_flank_tables(E);
-        if (E.B->dbg_n_cand) E.B->dbg_n_cand[g.gapNo] = 0;
-        if (E.B->draw_len) { E.B->draw_len[(long long)g.gapNo * 2] = -1; E.B->draw_len[(long long)g.gapNo * 2 + 1] = -1; }
-    }
-    for (int r = E.tid; r < nU; r += E.nt) {
-        E.scr.saved[r] = 0; E.scr.mark[r] = 0; E.scr.org[r * 2] = -200; E.scr.org[r * 2 + 1] = 0;
-        E.scr.frp[r * 2] = -200; E.scr.frp[r * 2 + 1] = 0;
-        if (E.B->draw_pos) E.B->draw_pos[g.uBase + r] = (int)0x80000000;
-    }
-    for (int p = E.tid; p < g.nP; p += E.nt) {
-        E.scr.ppos_org[p * 3] = 0; E.scr.ppos_org[p * 3 + 1] = -200; E.scr.ppos_org[p * 3 + 2] = 0;
-        if (E.B->draw_pos) E.B->draw_pos[E.B->n_ureads + g.pBase + p] = (int)0x80000000;
-    }
-    FIG_SYNC();
-    int finalize_flag = 1;
-    if (M.unmapped) { if (S.large_gap_flag == 0) finalize_flag = 0; }
-    // ---- analyzeGap: findGapLeftRight + findRepeat
-    if (E.tid == 0) {
-        S.G = G0; fig_ise(E);
-        int n = 0;
-        for (int k = S.side_limit; k >= 1; k--) S.gap_left[n++] = (unsigned char)fig_flank_l(E, k);   // last side_limit bases before the gap
-        S.gl_len = S.left < S.side_limit ? S.left : n;
-        if (S.left < S.side_limit) { n = 0; for (int k = S.left; k >= 1; k--) S.gap_left[n++] = (unsigned char)fig_flank_l(E, k); S.gl_len = n; }
-        n = 0;
-        for (int k = 0; k < S.right && n < S.side_limit; k++) {
-            long long abs = g.gapStart + G0 + k;
-            S.gap_right[n++] = (unsigned char)(abs < g.contigLen ? fig_flank_r(E, k) : 255);
-        }
-        S.gr_len = n;
-    }
-    FIG_SYNC();
-    fig_find_repeat(E);
-    float gp_frac1 = g.gpf1, gp_frac2 = g.gpf2;
-    int inr;
-    {
-        int skip = 0;
-        if (S.rep_flag == 1 && M.partial_flag) skip = 1;
-        else if (S.one_side_repeat_flag == 1 && M.partial_flag && G0 > 3 * (2 * M.partial_len)) skip = 1;
-        else if (g.fillflag == -1) skip = 1;
-        else if (S.partial_read_count == 0 && nU == 0) skip = 1;
-        inr = !skip;                                     // g in [0, 765466] / [0, 965757] otherwise (gap ids beyond that are not filled)
-        if (inr && g.gapNo > (M.script_itr == 1 ? 765466 : 965757)) inr = 0;
-    }
-    if (E.tid == 0) S.num_itr = inr ? 200 : 0;
-    if (!inr) { gp_frac1 = 1; gp_frac2 = 1; }
-    int gapMin = (int)(G0 * gp_frac1);
-    int gapMax = (int)(G0 * gp_frac2);
-    int gapEstimate = gapMin, maxGapEstimate = gapMin;
-    double maxLikelihood = -FIG_DBL_MAX, secondMaxLikelihood = -FIG_DBL_MAX;
-    double likelihood = 0, prevlikelihood = 0;
-    int fill_or_not = 0;
-    int same_count = 0, same_thresh = M.unmapped ? 50 : 4, stuckCount = 0;
-    int range = gapMax - gapMin + 1;
-    if (range > E.B->capC) range = E.B->capC;            // host sizes capC from the same formula; defensive
-    int side_flag = 0, j = 0;
-    int less_read_flag = 0;
-    FIG_SYNC();
-    if (M.unmapped && G0 <= M.unm_limit && inr) less_read_flag = fig_check_gap_reads<LDS>(E, G0);
-    if (less_read_flag == 1) range = 0;
-    if (less_read_flag == -2) { side_flag = 1; range = 0; }
-    int prev_best = -1, curr_best = 0, prev_u = -1, curr_u = 0, sec_same = 0, sec_same2 = 0;
-
-    for (; j < range; j++) {
-        if (E.tid == 0) S.umaxleftf = S.umaxrightf = S.ucoverf = 0;
-        fill_or_not = fig_initialize(E, gapEstimate, j);
-        if (S.side_limit < 10) { side_flag = 1; break; }
-        if (S.one_side_repeat_flag == 1) fill_or_not = 0;
-        if (fill_or_not != 0 && inr) break;
-        int i = 0;
-        if (E.tid == 0) { S.discont_or_not = 0; S.comp_count = 0; S.overlap_threshold = 5; S.lik = 0; }
-        FIG_SYNC();
-        int preset_unfilled_len = 2 * M.read_length;
-        for (i = 0; i < S.num_itr; i++) {
-            if (E.tid == 0) { S.valid_count = 0; S.invalid_count = 0; }
-            FIG_SYNC();
-            fig_place_reads<LDS>(E, i, finalize_flag, gapEstimate - G0, S.large_gap_flag);
-            fig_compute_probs(E);
-            FIG_SYNC();
-            if (M.unmapped) {
-                if (S.comp_count >= 5) break;
-                if (S.large_gap_flag == 1 && S.region_perct * gapEstimate < preset_unfilled_len) break;
-            } else { if (i == 2) break; }
-        }
-        if (M.unmapped && !finalize_flag && inr) {
-            if (E.tid == 0) S.valid_count = 0;
-            FIG_SYNC();
-            fig_place_reads<LDS>(E, i, 1, gapEstimate - G0, 0);
-        }
-        likelihood = S.lik;
-        fig_compute_sequence(E, 0, 0);
-        int valid_count = S.valid_count;
-        if (E.tid == 0) fig_dbg_cand(E, gapEstimate, i, valid_count, likelihood);
-        if (likelihood > maxLikelihood) {
-            secondMaxLikelihood = maxLikelihood;
-            maxLikelihood = likelihood;
-            maxGapEstimate = gapEstimate;
-            fig_copy_str(E, E.scr.best, &S.best_len, E.scr.cons, S.cons_len);
-            for (int k = E.tid; k < nU; k += E.nt) E.scr.saved[k] = E.scr.mark[k];
-            if (E.tid == 0) { S.region_perct_max = S.region_perct; S.psr_final[0] = S.psr_temp[0]; S.psr_final[1] = S.psr_temp[1]; }
-            curr_best = j;
-            prev_u = valid_count;
-        } else if (likelihood > secondMaxLikelihood) secondMaxLikelihood = likelihood;
-        if (E.tid == 0 && j < E.B->capC) { E.scr.used_read_arr[j] = valid_count; E.scr.lrmd[j * 2] = S.left; E.scr.lrmd[j * 2 + 1] = S.right; }
-        if (gapEstimate == G0) fig_copy_str(E, E.scr.orig, &S.orig_len, E.scr.cons, S.cons_len);
-        FIG_SYNC();
-        if (M.partial_flag || M.unmapped) {
-            double diff1 = prevlikelihood - likelihood; if (diff1 < 0) diff1 = -diff1;
-            if (diff1 <= 0.9) same_count++; else same_count = 0;
-            prevlikelihood = likelihood;
-            if (same_count == same_thresh && S.G >= G0) break;
-            else if (same_count == same_thresh && S.G < G0) { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
-            if (M.unmapped) {
-                curr_u = valid_count;
-                int du = curr_u - prev_u; if (du < 0) du = -du;
-                if (curr_best == prev_best && du <= 2) sec_same++;
-                else { prev_best = curr_best; sec_same = 0; }
-                if (sec_same >= 2 * same_thresh) {
-                    if (S.G >= G0) break;
-                    else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
-                }
-                if (G0 <= 30) {
-                    if (!(S.umaxleftf == 1 || S.umaxrightf == 1 || S.ucoverf == 1)) sec_same2++; else sec_same2 = 0;
-                    if (sec_same2 >= 1.5 * same_thresh) {
-                        if (S.G >= G0) break;
-                        else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
-                    }
-                }
-                if (S.discont_or_not == 1 && valid_count < 5) stuckCount++; else stuckCount = 0;
-                if (stuckCount > 3 * same_thresh) {
-                    if (S.G >= G0) break;
-                    else { fig_run_original<LDS>(E, E.scr.orig, &S.orig_len); break; }
-                }
-            }
-        }
-        gapEstimate++;
-        FIG_SYNC();
-    }
-    FIG_SYNC();
-
-    if (fill_or_not != 0 && inr) {
-        if (E.tid == 0) { S.G = 0; S.gaptofill = fill_or_not; }
-    } else if (inr) {
-        if (M.unmapped) {
-            if (less_read_flag == 1) {
-                fig_run_original<LDS>(E, E.scr.orig, &S.orig_len);
-                fig_finalize<LDS>(E, G0);
-            } else if (side_flag) {
-                fig_run_original<LDS>(E, E.scr.best, &S.best_len);
-                fig_finalize<LDS>(E, G0);
-            } else {
-                int changed = 0;                         // check_change(used_read_arr, j), :5886-5895
-                if (j != 1) for (int i = 1; i < j && i < E.B->capC; i++) if (E.scr.used_read_arr[0] != E.scr.used_read_arr[i]) { changed = 1; break; }
-                if (changed) fig_finalize<LDS>(E, maxGapEstimate);
-                else { fig_copy_str(E, E.scr.best, &S.best_len, E.scr.orig, S.orig_len); fig_finalize<LDS>(E, G0); }
-            }
-        } else {
-            if (maxGapEstimate == 0) {
-                if (E.scr.used_read_arr[0] != 0) fig_finalize<LDS>(E, maxGapEstimate);
-                else {
-                    if (maxGapEstimate < G0) fig_run_original<LDS>(E, E.scr.orig, &S.orig_len);
-                    fig_finalize<LDS>(E, G0);
-                }
-            } else {
-                if (side_flag) {
-                    int idx = maxGapEstimate - gapMin;
-                    if (E.tid == 0 && idx >= 0 && idx < E.B->capC) { S.left = E.scr.lrmd[idx * 2]; S.right = E.scr.lrmd[idx * 2 + 1]; }
-                    FIG_SYNC();
-                }
-                fig_finalize<LDS>(E, maxGapEstimate);
-            }
-        }
-    }
-    FIG_SYNC();
-    // ---- output (getConcensus :4510-4522, gapout line :7411-7413)
-    int len = S.G;
-    const char A[5] = {'A', 'C', 'G', 'T', 'N'};
-    char *dst = E.B->str + g.strOff;
-    for (int x = E.tid; x < len && x < g.alloc_arg; x += E.nt) {
-        int c = x < S.cons_len ? E.scr.cons[x] : 4;
-        dst[x] = A[c > 4 ? 4 : c];
-    }
-    if (E.tid == 0) { E.B->filled_len[g.gapNo] = len; E.B->gaptofill[g.gapNo] = S.gaptofill; }
-    (void)cg;
-    FIG_SYNC();
-}
+#include "fig_engine_sched.h"

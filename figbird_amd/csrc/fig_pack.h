@@ -9,6 +9,7 @@
 #include <vector>
 #include "../../include/figbird_hip.h"
 #include "fig_types.h"
+// (fig_engine.h must already be included: fig_persist_layout / FigState sizes come from it)
 
 // findFrac + alloc_arg, Figbird.cpp:6879-6906, :7393-7400 (float arithmetic as in the reference)
 static void gap_alloc(const fig_model *m, int G0, int *alloc_arg, float *f1, float *f2, int *lgf) {
@@ -72,7 +73,8 @@ struct FigPacked {
     std::vector<int64_t> u_woff, p_woff, p_qoff, str_off;
     std::vector<FigLaunchClass> classes;
     int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0, capE = 0;
-    int64_t str_total = 0, n_gaps = 0;
+    int64_t str_total = 0, n_gaps = 0, persist_total = 0;
+    int nslots = 32;
     int64_t packed_bytes() const {
         return (int64_t)(packed.size() * 4 + flank.size() + gaps.size() * sizeof(FigDevGap) + qual.size() +
                          (u_pos.size() * 3 + p_pos.size() * 5) * 4 + (u_woff.size() + p_woff.size() + p_qoff.size()) * 8);
@@ -162,6 +164,17 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         int gm = std::max(d.G0, (int)(d.G0 * d.gpf2));
         if (m->unmapped_flag && d.G0 <= m->unm_limit) gm = std::max(gm, d.G0 < 30 ? 70 : 3 * d.G0);
         gmax[g] = std::min(gm, d.alloc_arg);
+    }
+    // per-gap persistent slabs of the candidate-parallel scheduler
+    {
+        long long off = 0;
+        for (int64_t g = 0; g < ng; g++) {
+            FigDevGap &d = K.gaps[g];
+            d.capGg = (gmax[g] + 7) & ~7; d.rangeCap = gap_range(d.G0, d.gpf1, d.gpf2); d.nslots = K.nslots; d.pad = 0;
+            d.persistOff = off;
+            off += (fig_persist_layout(nullptr, d.capGg, d.nU, d.nP, d.rangeCap, d.nslots, state_bytes, nullptr) + 255) & ~255LL;
+        }
+        K.persist_total = off;
     }
     struct ClsDef { int capGl, nt; };
     const ClsDef defs[] = {{448, 256}, {1216, 512}, {1 << 30, 512}};

@@ -38,6 +38,8 @@ struct FigDevGap {
     int64_t flankOff;                // byte offset of this gap's 2*FIG_FLANK flank codes
     int64_t strOff;                  // offset of this gap's result string
     int32_t gapNo; int32_t cls;
+    int64_t persistOff;              // this gap's persistent slab (candidate-parallel mode)
+    int32_t capGg, rangeCap, nslots, pad;
 };
 
 struct FigDevReads {                 // batch-wide SoA, one entry per read
@@ -69,6 +71,8 @@ struct FigDevBatch {
     uint8_t *scratch; int64_t scratch_stride;   // one slab per workgroup
     int32_t capG, capR, capP, capC;  // capacities the slab was carved for (columns, unmapped reads, partial reads, candidates)
     int32_t capW, capE;              // weight-buffer doubles, extended-table columns
+    uint8_t *persist;                // per-gap persistent slabs
+    int32_t *gapctl;                 // [n_gaps*4] {status (0 finished, 1 more candidates, 2 loop done), next j, range, -}
 };
 
 #endif

@@ -101,6 +101,10 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     std::vector<unsigned char> slab((size_t)stride + 64, 0);
     B.scratch = slab.data(); B.scratch_stride = stride;
     B.capG = K.capG; B.capR = K.capR; B.capP = K.capP; B.capC = K.capC; B.capW = K.capW; B.capE = K.capE;
+    std::vector<unsigned char> persist((size_t)K.persist_total + 256, 0);
+    B.persist = persist.data();
+    std::vector<int32_t> gapctl((size_t)ng * 4 + 4, 0);
+    B.gapctl = gapctl.data();
     const FigDevModel &M = ctx->dm;
     for (const FigLaunchClass &c : K.classes) {
         // one emulated lane = one wave of width 1; the class's team count is kept so the chunking logic runs
@@ -119,7 +123,61 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         unsigned char *bp = (unsigned char *)(E.S + 1);
         E.gs = bp; bp += ((c.capGl + 7) & ~7); E.rb = bp;
         E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
-        for (int qi = c.q_begin; qi < c.q_end; qi++) { E.g = &K.gaps[K.order[qi]]; fig_fill_gap<true>(E); }
+        FigScr work = E.scr;
+        const char *sched = getenv("FIG_SCHED");
+        const bool seq = sched && strcmp(sched, "seq") == 0;
+        auto persist_of = [&](const FigDevGap &g, FigPersist &P) { fig_persist_layout(B.persist + g.persistOff, g.capGg, g.nU, g.nP, g.rangeCap, g.nslots, sizeof(FigState), &P); };
+        if (seq) {
+            for (int qi = c.q_begin; qi < c.q_end; qi++) {
+                E.g = &K.gaps[K.order[qi]];
+                FigPersist P; persist_of(*E.g, P);
+                fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+                fig_fill_gap<true>(E);
+            }
+        } else {
+            // candidate-parallel schedule, executed in order (mirrors run_class_parallel in fig_abi.hip)
+            std::vector<int> ids(K.order.begin() + c.q_begin, K.order.begin() + c.q_end);
+            std::vector<int> status(K.gaps.size(), 0);
+            for (int gi : ids) {
+                E.g = &K.gaps[gi];
+                FigPersist P; persist_of(*E.g, P);
+                fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+                fig_gap_begin<true>(E);
+                if (!E.S->L.inr) { while (!E.S->L.done) { fig_eval_candidate<true>(E); fig_loop_step(E); } fig_gap_end<true>(E); status[gi] = 0; }
+                else { fig_state_save(E, P); status[gi] = E.S->L.done ? 2 : 1; }
+            }
+            const char *ce = getenv("FIG_EMU_CHUNK");
+            const int chunk = ce ? atoi(ce) : 5;
+            while (true) {
+                int n_active = 0;
+                for (int gi : ids) n_active += status[gi] == 1;
+                if (!n_active) break;
+                for (int gi : ids) {
+                    if (status[gi] != 1) continue;
+                    E.g = &K.gaps[gi];
+                    FigPersist P; persist_of(*E.g, P);
+                    const FigState *snap = (const FigState *)P.state;
+                    int j = snap->L.j, range = snap->L.range;
+                    int n = std::min(std::min(chunk, E.g->nslots), range - j);
+                    for (int k = n - 1; k >= 0; k--) {                      // any order; every item starts from poisoned scratch + LDS
+                        memset(slab.data(), 0xA5, slab.size()); memset(lds.data(), 0xA5, lds.size() * sizeof(double));
+                        fig_spec_eval<true>(E, work, P, j + k, k, E.g->capGg);
+                    }
+                    memset(slab.data(), 0xA5, slab.size()); memset(lds.data(), 0xA5, lds.size() * sizeof(double));
+                    fig_spec_replay(E, work, P, n, E.g->capGg);
+                    status[gi] = E.S->L.done ? 2 : 1;
+                }
+            }
+            for (int gi : ids) {
+                if (status[gi] != 2) continue;
+                E.g = &K.gaps[gi];
+                FigPersist P; persist_of(*E.g, P);
+                memset(slab.data(), 0xA5, slab.size()); memset(lds.data(), 0xA5, lds.size() * sizeof(double));
+                fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+                fig_state_load(E, P);
+                fig_gap_end<true>(E);
+            }
+        }
         counters[1] += E.flops;
     }
     ctx->stats.place_calls = (int64_t)counters[0]; ctx->stats.alg_flops = (double)counters[1];
