@@ -50,6 +50,7 @@ class FigGapResults(C.Structure):
         ("filled_len", c_i32_p), ("gaptofill", c_i32_p), ("str_off", c_i64_p), ("str", C.c_char_p),
         ("str_capacity", C.c_int64),
         ("dbg_max_cand", C.c_int32), ("dbg_n_cand", c_i32_p), ("dbg_cand_i", c_i32_p), ("dbg_cand_lik", c_double_p),
+        ("dbg_n_place", c_i32_p),
         ("draw_pos", c_i32_p), ("draw_isz", c_i32_p), ("draw_len", c_i32_p),
     ]
 
@@ -238,6 +239,7 @@ class FillResult:
     gaptofill: np.ndarray
     strings: List[str]
     cand: Optional[list] = None     # per gap: list of (gapEstimate, iterations, valid_count, likelihood)
+    n_place: Optional[np.ndarray] = None
 
     @property
     def filled_bases(self) -> int:
@@ -288,7 +290,8 @@ class Engine:
         if debug_cand > 0:
             dn = np.zeros(max(n, 1), dtype=np.int32); di = np.zeros(max(n, 1) * debug_cand * 3, dtype=np.int32)
             dl = np.zeros(max(n, 1) * debug_cand)
-            r.dbg_max_cand = debug_cand; r.dbg_n_cand = _p(dn, c_i32_p); r.dbg_cand_i = _p(di, c_i32_p); r.dbg_cand_lik = _p(dl, c_double_p)
+            dp = np.zeros(max(n, 1), dtype=np.int32)
+            r.dbg_max_cand = debug_cand; r.dbg_n_cand = _p(dn, c_i32_p); r.dbg_cand_i = _p(di, c_i32_p); r.dbg_cand_lik = _p(dl, c_double_p); r.dbg_n_place = _p(dp, c_i32_p)
         self._check(self.lib.fig_fill_resident(self.ctx, C.byref(r)), "fig_fill_resident")
         raw = st.tobytes()
         strings = [raw[so[g]:so[g + 1]].decode() for g in range(n)]
@@ -299,7 +302,9 @@ class Engine:
                 k = min(int(dn[g]), debug_cand)
                 base = g * debug_cand
                 cand.append([(int(di[(base + j) * 3]), int(di[(base + j) * 3 + 1]), int(di[(base + j) * 3 + 2]), float(dl[base + j])) for j in range(k)])
-        return FillResult(fl[:n].copy(), gt[:n].copy(), strings, cand)
+        res = FillResult(fl[:n].copy(), gt[:n].copy(), strings, cand)
+        res.n_place = dp[:n].copy() if debug_cand > 0 else None
+        return res
 
     def free_batch(self):
         self.lib.fig_batch_free(self.ctx)

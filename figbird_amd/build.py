@@ -28,6 +28,13 @@ HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-ffp-contract=off", "-fPIC", "-shared", "-std=c++17", "-Wno-unused-value"]
 
 
+def _csrc_files():
+    """Every source the device library / emulation depends on (all of csrc/ + the ABI header)."""
+    out = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".hip", ".cpp"))]
+    out.append(os.path.join(ROOT, "include", "figbird_hip.h"))
+    return out
+
+
 def _newer(target: str, sources) -> bool:
     if not os.path.exists(target):
         return False
@@ -45,8 +52,7 @@ def _run(cmd, **kw):
 
 def build_lib(force: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
-    srcs = [os.path.join(CSRC, f) for f in ("fig_abi.hip", "fig_engine.h", "fig_engine_core.h", "fig_engine_hot.h", "fig_types.h", "fig_pack.h")]
-    srcs.append(os.path.join(ROOT, "include", "figbird_hip.h"))
+    srcs = _csrc_files()
     if force or not _newer(LIB, srcs):
         _run([HIPCC] + HIP_FLAGS + ["-o", LIB, os.path.join(CSRC, "fig_abi.hip")])
     return LIB
@@ -74,7 +80,7 @@ def build_test_infra(force: bool = False) -> None:
             _run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
     host = os.path.join(CSRC, "host")
     srcs = [os.path.join(host, "figfill_main.cpp"), os.path.join(host, "fig_host.cpp"), os.path.join(host, "fig_host.h"),
-            os.path.join(ROOT, "tests", "emu", "fig_emu_abi.cpp")] + [os.path.join(CSRC, f) for f in ("fig_engine.h", "fig_engine_core.h", "fig_engine_hot.h", "fig_types.h", "fig_pack.h")]
+            os.path.join(ROOT, "tests", "emu", "fig_emu_abi.cpp")] + _csrc_files()
     if force or not _newer(EMU, srcs):
         _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", EMU, srcs[0], srcs[1], srcs[3]])
     if force or not _newer(EMULIB, srcs):

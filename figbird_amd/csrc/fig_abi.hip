@@ -519,7 +519,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     std::vector<void *> tmp;
     auto talloc = [&](size_t n, void **p) -> int { if (hipMalloc(p, n ? n : 8) != hipSuccess) return FIG_ENOMEM; tmp.push_back(*p); return FIG_OK; };
     auto tfree = [&]() { for (void *p : tmp) hipFree(p); };
-    db.dbg_n_cand = nullptr; db.dbg_cand_i = nullptr; db.dbg_cand_lik = nullptr; db.dbg_max_cand = 0;
+    db.dbg_n_cand = nullptr; db.dbg_cand_i = nullptr; db.dbg_cand_lik = nullptr; db.dbg_max_cand = 0; db.dbg_n_place = nullptr;
     db.draw_pos = db.draw_isz = db.draw_len = nullptr;
     void *p;
     if (out->dbg_n_cand && out->dbg_cand_i && out->dbg_cand_lik && out->dbg_max_cand > 0) {
@@ -528,6 +528,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         if (talloc((size_t)ng * out->dbg_max_cand * 12, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_cand_i = (int32_t *)p;
         if (talloc((size_t)ng * out->dbg_max_cand * 8, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_cand_lik = (double *)p;
         hipMemsetAsync(db.dbg_n_cand, 0, (size_t)ng * 4, ctx->stream);
+        if (out->dbg_n_place) { if (talloc((size_t)ng * 4, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_n_place = (int32_t *)p; hipMemsetAsync(db.dbg_n_place, 0, (size_t)ng * 4, ctx->stream); }
     }
     int64_t nr = ctx->n_ureads + ctx->n_preads;
     if (out->draw_pos && out->draw_isz && out->draw_len) {
@@ -573,6 +574,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         hipMemcpyAsync(out->dbg_n_cand, db.dbg_n_cand, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipMemcpyAsync(out->dbg_cand_i, db.dbg_cand_i, (size_t)ng * out->dbg_max_cand * 12, hipMemcpyDeviceToHost, ctx->stream);
         hipMemcpyAsync(out->dbg_cand_lik, db.dbg_cand_lik, (size_t)ng * out->dbg_max_cand * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (db.dbg_n_place) hipMemcpyAsync(out->dbg_n_place, db.dbg_n_place, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (db.draw_pos) {
         hipMemcpyAsync(out->draw_pos, db.draw_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, ctx->stream);

@@ -106,70 +106,66 @@ FIG_D double fig_hot_chain_e(const FigPQ *PQ, const double *Q4, int ncolE, fig_c
 }
 
 // Two placements per lane at once (same read => same scalar data): twice the independent work per
-// scalar-table fetch and two independent multiply chains to hide FP64 latency.
+// scalar-table fetch and two independent multiply chains to hide FP64 latency.  The chain is cut into 8-step
+// blocks; each block first issues its scalar table loads (32 SGPRs) and its 16 LDS reads, then runs the 64 FP64
+// ops, so the memory latencies overlap each other and (with a second wave on the SIMD) the arithmetic.
 template <bool LDS>
 FIG_D void fig_hot_chain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, int nw2, fig_cdp kt, int len, int xa, int xb, double &pa, double &pb) {
-    for (int wi = 0; wi < nw2; wi++) {
-        uint32_t w = pk[wi];
-        int j0 = wi * 16;
-        int nb = len - j0; if (nb > 16) nb = 16;
+    const int nblk = len >> 3;
+    for (int bi = 0; bi < nblk; bi++) {
+        const int j0 = bi * 8;
+        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
         fig_cdp k2 = kt + 2 * j0;
+        double kk[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) kk[q] = k2[q];
         const FigPQ *ca = PQ + xa + j0, *cb = PQ + xb + j0;
-        if (nb == 16) {
+        FigPQ va[8], vb[8];
 #pragma unroll
-            for (int h = 0; h < 2; h++) {
-                FigPQ va[8], vb[8];
+        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) { int q = h * 8 + jj; int r = (int)((w >> (2 * q)) & 3) * ncolE + q; va[jj] = ca[r]; vb[jj] = cb[r]; }
-#pragma unroll
-                for (int jj = 0; jj < 8; jj++) {
-                    int q = h * 8 + jj;
-                    double ome = k2[2 * q], e = k2[2 * q + 1];
-                    pa *= (va[jj].p * ome + e * va[jj].q);
-                    pb *= (vb[jj].p * ome + e * vb[jj].q);
-                }
-            }
-        } else {
-            for (int jj = 0; jj < nb; jj++) {
-                double ome = k2[2 * jj], e = k2[2 * jj + 1];
-                int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj;
-                FigPQ va = ca[r], vb = cb[r];
-                pa *= (va.p * ome + e * va.q);
-                pb *= (vb.p * ome + e * vb.q);
-            }
+        for (int jj = 0; jj < 8; jj++) {
+            pa *= (va[jj].p * kk[2 * jj] + kk[2 * jj + 1] * va[jj].q);
+            pb *= (vb[jj].p * kk[2 * jj] + kk[2 * jj + 1] * vb[jj].q);
         }
+    }
+    for (int j = nblk * 8; j < len; j++) {
+        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
+        const double ome = kt[2 * j], e = kt[2 * j + 1];
+        const FigPQ va = PQ[b * ncolE + xa + j], vb = PQ[b * ncolE + xb + j];
+        pa *= (va.p * ome + e * va.q);
+        pb *= (vb.p * ome + e * vb.q);
     }
 }
 
 template <bool LDS>
 FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, fig_cdp mt, int len, int xa, int xb, double &qa, double &qb) {
-    for (int wi = 0; wi < nw2; wi++) {
-        uint32_t w = pk[wi];
-        int j0 = wi * 16;
-        int nb = len - j0; if (nb > 16) nb = 16;
+    const int nblk = len >> 3;
+    for (int bi = 0; bi < nblk; bi++) {
+        const int j0 = bi * 8;
+        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
         fig_cdp k2 = mt + 2 * j0;
+        double kk[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) kk[q] = k2[q];
         const double *ca = C + xa + j0, *cb = C + xb + j0;
-        if (nb == 16) {
-            double va[16], vb[16];
+        double va[8], vb[8];
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
+        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
 #pragma unroll
-            for (int jj = 0; jj < 16; jj++) {
-                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
-                double fa = e * va[jj], fb = e * vb[jj];
-                qa *= (va[jj] < 0 ? m3 : fa);
-                qb *= (vb[jj] < 0 ? m3 : fb);
-            }
-        } else {
-            for (int jj = 0; jj < nb; jj++) {
-                double m3 = k2[2 * jj], e = k2[2 * jj + 1];
-                int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj;
-                double va = ca[r], vb = cb[r];
-                double fa = e * va, fb = e * vb;
-                qa *= (va < 0 ? m3 : fa);
-                qb *= (vb < 0 ? m3 : fb);
-            }
+        for (int jj = 0; jj < 8; jj++) {
+            const double fa = kk[2 * jj + 1] * va[jj], fb = kk[2 * jj + 1] * vb[jj];
+            qa *= (va[jj] < 0 ? kk[2 * jj] : fa);
+            qb *= (vb[jj] < 0 ? kk[2 * jj] : fb);
         }
+    }
+    for (int j = nblk * 8; j < len; j++) {
+        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
+        const double m3 = mt[2 * j], e = mt[2 * j + 1];
+        const double va = C[b * ncolE + xa + j], vb = C[b * ncolE + xb + j];
+        const double fa = e * va, fb = e * vb;
+        qa *= (va < 0 ? m3 : fa);
+        qb *= (vb < 0 ? m3 : fb);
     }
 }
 

@@ -249,6 +249,7 @@ FIG_D void fig_gap_end(FigEng &E) {
     if (E.tid == 0) {
         E.B->filled_len[g.gapNo] = len; E.B->gaptofill[g.gapNo] = S.gaptofill;
         fig_atomic_add_u64(&E.B->counters[0], (unsigned long long)S.n_place);
+        if (E.B->dbg_n_place) E.B->dbg_n_place[g.gapNo] = S.n_place;
         if (S.flops_useful) fig_atomic_add_u64(&E.B->counters[1], S.flops_useful);
     }
     FIG_SYNC();
@@ -275,12 +276,12 @@ FIG_D void fig_fill_gap(FigEng &E) {
 //
 //   [FigState snapshot][best][orig][prev][saved][org][ppos_org][repeatflag][used_read_arr][lrmd]
 //   [org_spec][ppos_spec]                      <- written by the candidate whose length == originalGap
-//   [slot 0 .. nslots-1]: {FigSlot header, consensus[capGg+8], mark_accepted[nU+8]}
+//   [slot 0 .. nslots-1]: {FigSlot header, consensus[capGg+8], previous_str[capGg+8], mark_accepted[nU+8]}
 struct FigSlot {
     double lik, region_perct;
     long long end_pos_max;
     unsigned long long flops;
-    int G, iters, valid, side_break, fill, flags, psr0, psr1, left, right, side_limit, cons_len, partial_read_len, partial_read_count, n_place, pad1;
+    int G, iters, valid, side_break, fill, flags, psr0, psr1, left, right, side_limit, cons_len, partial_read_len, partial_read_count, n_place, prev_len;
 };
 
 struct FigPersist {                  // pointers into one gap's persistent slab
@@ -305,7 +306,7 @@ FIG_HD long long fig_persist_layout(unsigned char *base, int capGg, int nU, int 
     FIG_PC(lrmd, int, 2LL * range + 4);
     FIG_PC(org_spec, int, 2LL * nU + 2);
     FIG_PC(ppos_spec, int, 3LL * nP + 3);
-    long long stride = fig_align8((long long)sizeof(FigSlot)) + fig_align8(capGg + 8) + fig_align8(nU + 8);
+    long long stride = fig_align8((long long)sizeof(FigSlot)) + 2 * fig_align8(capGg + 8) + fig_align8(nU + 8);
     if (p) { p->slots = base + o; p->slot_stride = stride; }
     o += stride * nslots;
 #undef FIG_PC
@@ -314,7 +315,8 @@ FIG_HD long long fig_persist_layout(unsigned char *base, int capGg, int nU, int 
 
 FIG_D FigSlot *fig_slot_hdr(const FigPersist &P, int s) { return (FigSlot *)(P.slots + P.slot_stride * s); }
 FIG_D unsigned char *fig_slot_cons(const FigPersist &P, int s) { return P.slots + P.slot_stride * s + fig_align8((long long)sizeof(FigSlot)); }
-FIG_D unsigned char *fig_slot_mark(const FigPersist &P, int s, int capGg) { return fig_slot_cons(P, s) + fig_align8(capGg + 8); }
+FIG_D unsigned char *fig_slot_prev(const FigPersist &P, int s, int capGg) { return fig_slot_cons(P, s) + fig_align8(capGg + 8); }
+FIG_D unsigned char *fig_slot_mark(const FigPersist &P, int s, int capGg) { return fig_slot_cons(P, s) + 2 * fig_align8(capGg + 8); }
 
 // LDS state <-> persistent snapshot (all lanes; ends with a barrier)
 FIG_D void fig_state_save(FigEng &E, const FigPersist &P) {
@@ -374,9 +376,13 @@ FIG_D void fig_spec_eval(FigEng &E, const FigScr &work, const FigPersist &P, int
         h->flags = (S.umaxleftf ? 1 : 0) | (S.umaxrightf ? 2 : 0) | (S.ucoverf ? 4 : 0) | (S.discont_or_not ? 8 : 0);
         h->psr0 = S.psr_temp[0]; h->psr1 = S.psr_temp[1];
         h->left = S.left; h->right = S.right; h->side_limit = S.side_limit; h->cons_len = S.cons_len;
-        h->partial_read_len = S.partial_read_len; h->partial_read_count = S.partial_read_count; h->n_place = S.n_place;
+        h->partial_read_len = S.partial_read_len; h->partial_read_count = S.partial_read_count; h->n_place = S.n_place; h->prev_len = S.prev_len;
     }
     FIG_SYNC();
+    {   // previous_str as this candidate leaves it (:3919-3927): the next sequential step (the run(originalGap) fallbacks) compares against it
+        unsigned char *pv = fig_slot_prev(P, slot, capGg);
+        for (int x = E.tid; x < S.prev_len; x += E.nt) pv[x] = E.scr.prev[x];
+    }
     if (E.flops != flops0) fig_atomic_add_u64(&fig_slot_hdr(P, slot)->flops, E.flops - flops0);
     E.flops = flops0;                             // speculative work is credited by the replay, and only if it is consumed
     FIG_SYNC();
@@ -404,6 +410,11 @@ FIG_D void fig_spec_replay(FigEng &E, const FigScr &work, const FigPersist &P, i
         if (h->G == G0 && !h->side_break && !(h->fill != 0 && S.L.inr)) {     // this candidate's placeReads ran with gapLength == originalGap
             for (int i = E.tid; i < 2 * nU; i += E.nt) P.org[i] = P.org_spec[i];
             for (int i = E.tid; i < 3 * nP; i += E.nt) P.ppos_org[i] = P.ppos_spec[i];
+        }
+        if (!h->side_break && !(h->fill != 0 && S.L.inr) && S.num_itr > 0) {
+            const unsigned char *pv = fig_slot_prev(P, s, capGg);
+            for (int x = E.tid; x < h->prev_len; x += E.nt) P.prev[x] = pv[x];
+            if (E.tid == 0) S.prev_len = h->prev_len;
         }
         fig_loop_step(E);
     }

@@ -62,7 +62,7 @@ struct FigDevBatch {
     const uint8_t *flank;            // per-gap flank codes
     // outputs
     int32_t *filled_len, *gaptofill; char *str;
-    int32_t dbg_max_cand; int32_t *dbg_n_cand; int32_t *dbg_cand_i; double *dbg_cand_lik;
+    int32_t dbg_max_cand; int32_t *dbg_n_cand; int32_t *dbg_cand_i; double *dbg_cand_lik; int32_t *dbg_n_place;
     int32_t *draw_pos, *draw_isz, *draw_len; int64_t n_ureads;
     // work queue + counters
     int32_t *queue_head;             // [1] next index into order[]

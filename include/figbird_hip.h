@@ -108,6 +108,7 @@ typedef struct fig_gap_results {
     int32_t *dbg_n_cand;                /* [n_gaps]                                         */
     int32_t *dbg_cand_i;                /* [n_gaps*dbg_max_cand*3]                          */
     double *dbg_cand_lik;               /* [n_gaps*dbg_max_cand]                            */
+    int32_t *dbg_n_place;               /* [n_gaps] placeReads invocations spent on the gap (needs dbg_n_cand)  */
     /* optional per-read final placements for draw.txt (Figbird.cpp:5140, 5381); NULL to disable */
     int32_t *draw_pos;                  /* [n_ureads + n_preads] maxPos-left_maxDistance, or INT32_MIN if the read was not drawn */
     int32_t *draw_isz;                  /* [n_ureads + n_preads] mleInsertSize / newInsertSize */

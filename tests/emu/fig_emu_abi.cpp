@@ -92,6 +92,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     if (out->dbg_n_cand && out->dbg_cand_i && out->dbg_cand_lik && out->dbg_max_cand > 0) {
         B.dbg_max_cand = out->dbg_max_cand; B.dbg_n_cand = out->dbg_n_cand; B.dbg_cand_i = out->dbg_cand_i; B.dbg_cand_lik = out->dbg_cand_lik;
         for (int64_t g = 0; g < ng; g++) out->dbg_n_cand[g] = 0;
+        B.dbg_n_place = out->dbg_n_place;
     }
     if (out->draw_pos && out->draw_isz && out->draw_len) { B.draw_pos = out->draw_pos; B.draw_isz = out->draw_isz; B.draw_len = out->draw_len; }
     B.n_ureads = (int64_t)K.u_pos.size();
