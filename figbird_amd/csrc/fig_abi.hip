@@ -53,6 +53,9 @@ FIG_D void fig_persist_of(const FigDevBatch &B, const FigDevGap &g, FigPersist &
     fig_persist_layout(B.persist + g.persistOff, g.capGg, g.nU, g.nP, g.rangeCap, g.nslots, sizeof(FigState), &P);
 }
 
+#ifndef FIG_WPE
+#define FIG_WPE 2          /* min waves per SIMD the kernels are register-allocated for (512-thread blocks: 2 => 1 block/CU.. ) */
+#endif
 // ---- sequential mode: whole gaps, one workgroup each (FIG_SCHED=seq)
 template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
@@ -588,8 +591,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->stats.d2h_ms = ms;
 #ifdef FIG_PROF
-    { const char *nm[9] = {"E.phaseA", "E.phaseB", "M.chains", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post"};
-      for (int i = 0; i < 9; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
+    { const char *nm[11] = {"E.phaseA", "E.phaseB", "M.chains", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0"};
+      for (int i = 0; i < 11; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
 #endif
     ctx->stats.place_calls = (int64_t)cnt[0];
     ctx->stats.alg_flops = (double)cnt[1];

@@ -76,14 +76,16 @@ static double *fig_lds = nullptr;
 typedef const uint32_t *fig_cu32p;
 typedef const double *fig_cdp;
 #else
-extern __shared__ double fig_lds[];
+extern __shared__ __attribute__((aligned(16))) double fig_lds[];
 #define FIG_RFL(x) __builtin_amdgcn_readfirstlane(x)
 // constant address space: uniform loads through these become scalar (s_load) instructions
 typedef const uint32_t __attribute__((address_space(4))) *fig_cu32p;
 typedef const double __attribute__((address_space(4))) *fig_cdp;
 #endif
 
-struct FigPQ { double p, q; };       // probsGap[x][b], errorProbsGap[x][b] of one (column, base)
+// 16-byte aligned so that the hot loop fetches a {P,Q} pair with ONE ds_read_b128 (256 B/clk/CU);
+// the ds_read2_b64 the compiler emits for an 8-byte-aligned pair is 2-way bank-conflicted at this stride.
+struct alignas(16) FigPQ { double p, q; };       // probsGap[x][b], errorProbsGap[x][b] of one (column, base)
 
 // Loop-carried variables of fillGap's candidate-length loop (Figbird.cpp:6237-6296), kept in memory so the
 // loop can be cut into pieces: begin (setup + checkGapReads), per-candidate evaluation, per-candidate
@@ -156,6 +158,7 @@ struct FigScr {
     int *org;          // unmapped_read_pos_arr_org [R][2]
     int *fin;          // finalize's unmapped_read_pos_arr [R][2]
     FigTrip *sortbuf;  // [R]
+    int *hint;         // [R] best placement of the previous MLE pass over this read (pruning hint only; never affects results)
     // per partial read
     int *repeatflag;   // [P][3]
     int *ppos_org;     // partial_read_pos_arr_org [P][3]
@@ -168,7 +171,7 @@ struct FigScr {
     double *wg;        // global weight buffer when it does not fit in LDS
 };
 
-FIG_HD long long fig_align8(long long x) { return (x + 7) & ~7LL; }
+FIG_HD long long fig_align8(long long x) { return (x + 15) & ~15LL; }   // (16: FigPQ rows want ds_read_b128 / dwordx4 alignment)
 
 // Carve the slab.  Returns the total size when base == nullptr.
 // capG = scratch columns (max alloc_arg), capE = extended table columns, capW = weight-buffer doubles
@@ -190,6 +193,7 @@ FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int
     FIG_CARVE(org, int, 2LL * capR);
     FIG_CARVE(fin, int, 2LL * capR);
     FIG_CARVE(sortbuf, FigTrip, capR);
+    FIG_CARVE(hint, int, capR);
     FIG_CARVE(repeatflag, int, 3LL * capP);
     FIG_CARVE(ppos_org, int, 3LL * capP);
     FIG_CARVE(pflag, int, 2LL * capP);

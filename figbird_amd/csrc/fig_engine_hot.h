@@ -57,6 +57,22 @@ FIG_D long long fig_u64(long long w) {
 #endif
 }
 
+FIG_D double fig_wave_max(double v) {
+#ifdef FIG_EMU
+    return v;
+#else
+    for (int off = 32; off > 0; off >>= 1) { double y = __shfl_xor(v, off, 64); v = y > v ? y : v; }
+    return v;
+#endif
+}
+FIG_D bool fig_wave_any(bool p) {
+#ifdef FIG_EMU
+    return p;
+#else
+    return __any(p) != 0;
+#endif
+}
+
 template <bool LDS> FIG_D const FigPQ *fig_pq_ptr(const FigEng &E) { return LDS ? (const FigPQ *)(fig_lds + fig_u(E.off_pq)) : fig_uptr(E.pq); }
 template <bool LDS> FIG_D const double *fig_q4_ptr(const FigEng &E) { return LDS ? (const double *)(fig_lds + fig_u(E.off_q4)) : fig_uptr(E.q4); }
 template <bool LDS> FIG_D double *fig_w_ptr(const FigEng &E) { return LDS ? (double *)(fig_lds + fig_u(E.off_w)) : fig_uptr(E.wbuf); }
@@ -109,25 +125,48 @@ FIG_D double fig_hot_chain_e(const FigPQ *PQ, const double *Q4, int ncolE, fig_c
 // scalar-table fetch and two independent multiply chains to hide FP64 latency.  The chain is cut into 8-step
 // blocks; each block first issues its scalar table loads (32 SGPRs) and its 16 LDS reads, then runs the 64 FP64
 // ops, so the memory latencies overlap each other and (with a second wave on the SIMD) the arithmetic.
+struct FigEBlk { double kk[16]; FigPQ va[8], vb[8]; };
+
+template <bool LDS>
+FIG_D void fig_eblk_load(FigEBlk &B, const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, int bi, int xa, int xb) {
+    const int j0 = bi * 8;
+    const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
+    fig_cdp k2 = kt + 2 * j0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) B.kk[q] = k2[q];
+    const FigPQ *ca = PQ + xa + j0, *cb = PQ + xb + j0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; B.va[jj] = ca[r]; B.vb[jj] = cb[r]; }
+}
+FIG_D void fig_eblk_compute(const FigEBlk &B, double &pa, double &pb) {
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        pa *= (B.va[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.va[jj].q);
+        pb *= (B.vb[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.vb[jj].q);
+    }
+}
+
+// Software-pipelined: the loads of block i+1 (scalar table + 16 LDS reads) are issued before the 64 FP64 ops
+// of block i, so their latency is covered by arithmetic of the same wave.
 template <bool LDS>
 FIG_D void fig_hot_chain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, int nw2, fig_cdp kt, int len, int xa, int xb, double &pa, double &pb) {
     const int nblk = len >> 3;
-    for (int bi = 0; bi < nblk; bi++) {
-        const int j0 = bi * 8;
-        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
-        fig_cdp k2 = kt + 2 * j0;
-        double kk[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) kk[q] = k2[q];
-        const FigPQ *ca = PQ + xa + j0, *cb = PQ + xb + j0;
-        FigPQ va[8], vb[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            pa *= (va[jj].p * kk[2 * jj] + kk[2 * jj + 1] * va[jj].q);
-            pb *= (vb[jj].p * kk[2 * jj] + kk[2 * jj + 1] * vb[jj].q);
+    if (nblk > 0) {
+        FigEBlk A, Bk;
+        fig_eblk_load<LDS>(A, PQ, ncolE, pk, kt, 0, xa, xb);
+        int bi = 0;
+        for (; bi + 2 <= nblk - 1; bi += 2) {
+            fig_eblk_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+            fig_eblk_compute(A, pa, pb);
+            fig_eblk_load<LDS>(A, PQ, ncolE, pk, kt, bi + 2, xa, xb);
+            fig_eblk_compute(Bk, pa, pb);
         }
+        // here block `bi` is loaded in A; blocks bi+1 .. nblk-1 remain (0 or 1 of them)
+        if (bi + 1 <= nblk - 1) {
+            fig_eblk_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+            fig_eblk_compute(A, pa, pb);
+            fig_eblk_compute(Bk, pa, pb);
+        } else fig_eblk_compute(A, pa, pb);
     }
     for (int j = nblk * 8; j < len; j++) {
         const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
@@ -167,6 +206,43 @@ FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, f
         qa *= (va < 0 ? m3 : fa);
         qb *= (vb < 0 ? m3 : fb);
     }
+}
+
+// MLE pair chain with exact pruning.  Every factor is <= 1, so a partial product only shrinks: once both partial
+// products of every lane of the wave are below `bound` (a product some placement of this read has already
+// ACHIEVED), none of them can be the arg-max and the rest of the round is skipped.  Returns false if pruned.
+template <bool LDS>
+FIG_D bool fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
+                             double bound, double &qa, double &qb) {
+    const int nblk = len >> 3;
+    for (int bi = 0; bi < nblk; bi++) {
+        const int j0 = bi * 8;
+        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
+        fig_cdp k2 = mt + 2 * j0;
+        double kk[16];
+#pragma unroll
+        for (int q = 0; q < 16; q++) kk[q] = k2[q];
+        const double *ca = C + xa + j0, *cb = C + xb + j0;
+        double va[8], vb[8];
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) {
+            const double fa = kk[2 * jj + 1] * va[jj], fb = kk[2 * jj + 1] * vb[jj];
+            qa *= (va[jj] < 0 ? kk[2 * jj] : fa);
+            qb *= (vb[jj] < 0 ? kk[2 * jj] : fb);
+        }
+        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+    }
+    for (int j = nblk * 8; j < len; j++) {
+        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
+        const double m3 = mt[2 * j], e = mt[2 * j + 1];
+        const double va = C[b * ncolE + xa + j], vb = C[b * ncolE + xb + j];
+        const double fa = e * va, fb = e * vb;
+        qa *= (va < 0 ? m3 : fa);
+        qb *= (vb < 0 ? m3 : fb);
+    }
+    return true;
 }
 
 // MLE product chain of one placement.  C[to*ncolE + xe] = -1 when the consensus base equals `to`,
@@ -287,14 +363,15 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid;
     const int team = wave / T, wit = wave - team * T;
     const bool clipped = left < xoff;              // some placements start left of the window (gap near the contig start)
-    // CPL > 0: each lane owns CPL columns and keeps their 5 accumulators in registers for the whole E-step.
+    // Column pass work units = (base c in ACGT, 64-column tile): `nslots` of them, dealt round-robin to the waves;
+    // a lane keeps ONE accumulator per unit of its wave in registers for the whole E-step (CPL = units per wave).
+    // Reads with N bases add their N positions straight into countsGap[4] (lane = column, reads in order).
     // CPL == 0: generic fallback (very long gaps, and the one-lane CPU emulation): accumulate in E.scr.cnt.
-    double acc[CPL > 0 ? CPL : 1][5];
+    double acc[CPL > 0 ? CPL : 1];
 #pragma unroll
-    for (int m = 0; m < (CPL > 0 ? CPL : 1); m++) for (int b = 0; b < 5; b++) acc[m][b] = 0;
-    if (CPL == 0) {                                   // placeReads zeroed countsGap already (:3050-3056)
-        FIG_SYNC();
-    }
+    for (int m = 0; m < (CPL > 0 ? CPL : 1); m++) acc[m] = 0;
+    const int ntiles = (G + U.wsz - 1) / U.wsz, nslots = 4 * ntiles;
+    FIG_SYNC();                                       // placeReads zeroed countsGap already (:3050-3056)
 
     FIG_T0(E);
     for (int c0 = 0; c0 < nU; c0 += nteams) {
@@ -322,12 +399,15 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 for (; o + stride <= w.hi; o += 2 * stride) {
                     int ob = o + stride;
                     double pa = U.insd[w.tis0 + w.dir * o], pb = U.insd[w.tis0 + w.dir * ob];
+                    FIG_T0(E);
                     fig_hot_chain_e2<LDS>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    FIG_TICK(E, 9);
                     double ta = fig_log10(pa), tb = fig_log10(pb);
                     if (ta > best.v) { best.v = ta; best.o = o; }
                     if (tb > best.v) { best.v = tb; best.o = ob; }
                     wrow[o] = fig_exp(0.5 * ta);
                     wrow[ob] = fig_exp(0.5 * tb);
+                    FIG_TICK(E, 10);
                     nplace += 2;
                 }
             }
@@ -373,40 +453,42 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 continue;
             }
             const uint32_t cw0 = pk[nw2 + nwm], cw1 = pk[nw2 + nwm + 1];
-            const int n0 = (int)(cw0 & 255), n1 = (int)((cw0 >> 8) & 255), n2 = (int)((cw0 >> 16) & 255), n3 = (int)(cw0 >> 24), n4 = (int)(cw1 & 255);
-            typedef const unsigned char __attribute__((address_space(4))) *fig_cu8p_;
+            const int nb[4] = {(int)(cw0 & 255), (int)((cw0 >> 8) & 255), (int)((cw0 >> 16) & 255), (int)(cw0 >> 24)};
+            const int n4 = (int)(cw1 & 255);
+            const int ob4[4] = {0, nb[0], nb[0] + nb[1], nb[0] + nb[1] + nb[2]};
 #ifdef FIG_EMU
             const unsigned char *pl = (const unsigned char *)(pk + nw2 + nwm + 2);
 #else
+            typedef const unsigned char __attribute__((address_space(4))) *fig_cu8p_;
             fig_cu8p_ pl = (fig_cu8p_)(pk + nw2 + nwm + 2);
 #endif
-            int nmin = n0 < n1 ? n0 : n1; if (n2 < nmin) nmin = n2; if (n3 < nmin) nmin = n3;
-            const int o1 = n0, o2 = n0 + n1, o3 = n0 + n1 + n2, o4 = n0 + n1 + n2 + n3;
-            const double *wx[CPL > 0 ? CPL : 1];
 #pragma unroll
-            for (int m = 0; m < CPL; m++) { int x = tid + m * U.nt; wx[m] = wrow + (x < G ? x : 0); }
-            for (int k = 0; k < nmin; k++) {
-                const int j0 = pl[k], j1 = pl[o1 + k], j2 = pl[o2 + k], j3 = pl[o3 + k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) {
-                    acc[m][0] += wx[m][-j0]; acc[m][1] += wx[m][-j1]; acc[m][2] += wx[m][-j2]; acc[m][3] += wx[m][-j3];
+            for (int m = 0; m < CPL; m++) {
+                const int sl = wave + m * U.nw;
+                if (sl < nslots) {
+                    const int c = sl / ntiles, tile = sl - c * ntiles;
+                    const int x = tile * U.wsz + lane;
+                    const double *wx = wrow + (x < G ? x : 0);
+                    const int n = nb[c], o0 = ob4[c];
+                    double a = acc[m];
+                    int k = 0;
+                    for (; k + 4 <= n; k += 4) {               // 4 loads in flight, then the 4 ordered adds
+                        const int j0 = pl[o0 + k], j1 = pl[o0 + k + 1], j2 = pl[o0 + k + 2], j3 = pl[o0 + k + 3];
+                        const double w0 = wx[-j0], w1 = wx[-j1], w2 = wx[-j2], w3 = wx[-j3];
+                        a += w0; a += w1; a += w2; a += w3;
+                    }
+                    for (; k < n; k++) a += wx[-(int)pl[o0 + k]];
+                    acc[m] = a;
                 }
             }
-            for (int k = nmin; k < n0; k++) { const int j = pl[k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) acc[m][0] += wx[m][-j]; }
-            for (int k = nmin; k < n1; k++) { const int j = pl[o1 + k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) acc[m][1] += wx[m][-j]; }
-            for (int k = nmin; k < n2; k++) { const int j = pl[o2 + k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) acc[m][2] += wx[m][-j]; }
-            for (int k = nmin; k < n3; k++) { const int j = pl[o3 + k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) acc[m][3] += wx[m][-j]; }
-            for (int k = 0; k < n4; k++) { const int j = pl[o4 + k];
-#pragma unroll
-                for (int m = 0; m < CPL; m++) acc[m][4] += wx[m][-j]; }
+            if (n4 > 0) {
+                const int o4 = ob4[3] + nb[3];
+                for (int x = tid; x < G; x += U.nt) {
+                    double a = E.scr.cnt[4 * cg + x];
+                    for (int k = 0; k < n4; k++) a += wrow[x - (int)pl[o4 + k]];
+                    E.scr.cnt[4 * cg + x] = a;
+                }
+            }
         }
         FIG_SYNC();
         FIG_TICK(E, 1);
@@ -414,8 +496,12 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     if (CPL > 0) {
 #pragma unroll
         for (int m = 0; m < CPL; m++) {
-            int x = tid + m * U.nt;
-            if (x < G) for (int b = 0; b < 5; b++) E.scr.cnt[b * cg + x] = acc[m][b];
+            const int sl = wave + m * U.nw;
+            if (sl < nslots) {
+                const int c = sl / ntiles, tile = sl - c * ntiles;
+                const int x = tile * U.wsz + lane;
+                if (x < G) E.scr.cnt[c * cg + x] = acc[m];
+            }
         }
     }
     FIG_SYNC();
@@ -423,11 +509,14 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
 
 template <bool LDS>
 FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
-    int cpl = (E.S->G + E.nt - 1) / E.nt;
+    const int ntiles = (E.S->G + E.wsz - 1) / E.wsz;
+    const int cpl = (4 * ntiles + E.nw - 1) / E.nw;      // column-pass units per wave
     if (cpl <= 1) fig_hot_estep<LDS, 1>(E, gapoffset);
     else if (cpl == 2) fig_hot_estep<LDS, 2>(E, gapoffset);
-    else if (cpl == 3) fig_hot_estep<LDS, 3>(E, gapoffset);
-    else if (cpl == 4) fig_hot_estep<LDS, 4>(E, gapoffset);
+    else if (cpl <= 4) fig_hot_estep<LDS, 4>(E, gapoffset);
+    else if (cpl <= 6) fig_hot_estep<LDS, 6>(E, gapoffset);
+    else if (cpl <= 10) fig_hot_estep<LDS, 10>(E, gapoffset);
+    else if (cpl <= 16) fig_hot_estep<LDS, 16>(E, gapoffset);
     else fig_hot_estep<LDS, 0>(E, gapoffset);
 }
 
@@ -472,14 +561,32 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             const int stride = T * U.wsz;
             int o = w.lo + wit * U.wsz + lane;
             if (!hasN) {
-                for (; o + stride <= w.hi; o += 2 * stride) {
-                    int ob = o + stride;
+                // pair-rounds of this wave: round rr covers o = obase + 2*rr*stride (and + stride).  Start with the round
+                // that holds the previous pass's best placement: it almost always yields the final maximum, after which
+                // every other round is abandoned after its first 8-base block.
+                const int obase = w.lo + wit * U.wsz;               // lane 0 of round 0
+                const int span = w.hi - obase;                      // < 0: nothing for this wave
+                const int nrounds = span < 0 ? 0 : span / (2 * stride) + 1;
+                int r0 = 0;
+                { int h = fig_u(E.scr.hint[r]); if (h != FIG_NOPOS && h >= obase && h <= w.hi) r0 = (h - obase) / (2 * stride); if (r0 >= nrounds) r0 = 0; }
+                double bound = init;
+                for (int q = 0; q < nrounds; q++) {
+                    int rr = r0 + q; if (rr >= nrounds) rr -= nrounds;
+                    const int oa = obase + lane + 2 * rr * stride, ob = oa + stride;
+                    const bool va_ok = oa <= w.hi, vb_ok = ob <= w.hi;
                     double qa = 1, qb = 1;
-                    fig_hot_chain_m2<LDS>(C, ncolE, pk, nw2, mt, rs.len, o + xoff, ob + xoff, qa, qb);
-                    if (qa > best.v) { best.v = qa; best.o = o; }
-                    if (qb > best.v) { best.v = qb; best.o = ob; }
-                    nplace += 2;
+                    // out-of-window lanes read inside the table (clamped) and are ignored
+                    const int xa = (va_ok ? oa : w.hi) + xoff, xb = (vb_ok ? ob : w.hi) + xoff;
+                    bool full = fig_hot_chain_m2p<LDS>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, qa, qb);
+                    if (full) {
+                        if (va_ok && (qa > best.v || (qa == best.v && best.o != FIG_NOPOS && oa < best.o))) { best.v = qa; best.o = oa; }
+                        if (vb_ok && (qb > best.v || (qb == best.v && best.o != FIG_NOPOS && ob < best.o))) { best.v = qb; best.o = ob; }
+                        double m = fig_wave_max(best.o == FIG_NOPOS ? init : best.v);
+                        if (m > bound) bound = m;
+                    }
+                    nplace += (va_ok ? 1 : 0) + (vb_ok ? 1 : 0);
                 }
+                o = w.hi + 1;
             }
             for (; o <= w.hi; o += stride) {
                 double q = fig_hot_chain_m<LDS>(C, ncolE, pk, nw2, mt, rs.len, o + xoff);
@@ -497,6 +604,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             FigBest b; b.v = init; b.o = FIG_NOPOS;
             for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[team * T + k]; y.o = S.wv_o[team * T + k]; b = fig_best_merge(b, y); }
             int o = b.o == FIG_NOPOS ? -left : b.o;
+            if (lane == 0) E.scr.hint[r] = b.o;
             double mp = b.o == FIG_NOPOS ? init : b.v;
             double temp_log_val = -fig_log10(mp);
             bool acc = temp_log_val < U.cutoff;
