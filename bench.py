@@ -52,7 +52,7 @@ def main():
     ap.add_argument("--mode", default="unmapped", choices=["unmapped", "partial"])
     ap.add_argument("--seed", type=int, default=20260101)
     ap.add_argument("--cpu-baseline", type=int, default=1)
-    ap.add_argument("--cpu-sample-gaps", type=int, default=0, help="0 = one gap per host core (max 8)")
+    ap.add_argument("--cpu-sample-gaps", type=int, default=0, help="0 = six gaps per host core (all of the >400-bp bracket of a 512-gap batch)")
     args = ap.parse_args()
 
     import torch
@@ -162,7 +162,7 @@ def main():
                                "note": "path is FP64-ALU bound (~1e5-1e7 flop/byte); HBM figure reported because the north star asks for it"}}
 
     # ---- CPU baseline: rank 0, N=1 only; bounded sample (the >400-bp bracket: one candidate length, a few EM
-    # iterations, ~10 s per gap per core; a <=400-bp gap of this set costs 10^2-10^3 CPU-seconds)
+    # iterations, ~1-2 s per gap per core, six per core; a <=400-bp gap of this set costs 10^2-10^3 CPU-seconds)
     if rank == 0 and world == 1 and args.cpu_baseline:
         try:
             out["cpu_baseline"] = cpu_baseline(args, spec, batch, mc, res, eng, work)
@@ -181,7 +181,7 @@ def main():
 def cpu_baseline(args, spec, batch, mc, res, eng, work):
     from figbird_amd import synth, build as fbuild
     cores = min(os.cpu_count() or 1, 16)
-    k = args.cpu_sample_gaps or min(cores, 8)
+    k = args.cpu_sample_gaps or cores * 6
     G = np.asarray(batch.gap_len)
     if spec.mode == "unmapped":
         nread = np.diff(batch.u_read_off)

@@ -13,6 +13,8 @@
 #include <cstring>
 #include <new>
 #include <vector>
+#include <chrono>
+#include <thread>
 
 #include "../../include/figbird_hip.h"
 #include "fig_engine.h"
@@ -171,6 +173,11 @@ struct DevBuf {
     void *p = nullptr; size_t n = 0;
 };
 
+// Per-class scheduling lane: the classes of a batch run concurrently, each on its own stream with its own work
+// queue head, scratch slabs and item buffers, so that the tail of one class's round is filled by the other
+// classes' workgroups.
+struct FigLane { hipStream_t stream = nullptr; hipEvent_t done = nullptr; int32_t *queue_head = nullptr; uint8_t *scratch = nullptr; int *d_items = nullptr, *d_entries = nullptr; size_t cap = 0; };
+
 struct fig_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -187,12 +194,13 @@ struct fig_ctx {
     FigDevBatch db;
     std::vector<FigDevGap> h_gaps;
     std::vector<int32_t> h_order;
-    struct Cls { FigLaunchClass c; int blocks; };
+    struct Cls { FigLaunchClass c; int blocks; int capacity; };
     std::vector<Cls> classes;
     std::vector<DevBuf> bufs;
     int64_t n_gaps = 0, n_ureads = 0, n_preads = 0, str_total = 0;
     std::vector<int64_t> h_str_off;
-    int nslots = 32; int *d_items = nullptr, *d_entries = nullptr; size_t sched_cap = 0;
+    int nslots = 32;
+    std::vector<FigLane> lanes;
     fig_stats stats;
 };
 
@@ -262,6 +270,8 @@ static void free_batch(fig_ctx *ctx) {
     ctx->bufs.clear();
     ctx->have_batch = false;
     ctx->classes.clear();
+    for (auto &l : ctx->lanes) { if (l.stream) hipStreamDestroy(l.stream); if (l.done) hipEventDestroy(l.done); }
+    ctx->lanes.clear();
 }
 
 extern "C" void fig_batch_free(fig_ctx *ctx) {
@@ -361,8 +371,9 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
         c.c = lc;
         int per_cu = (int)std::max<size_t>(1, std::min<size_t>((160 * 1024) / std::max<size_t>(lc.lds, 1), (size_t)(2048 / lc.nt)));
         per_cu = std::min(per_cu, 8);
-        c.blocks = std::min<int>(lc.q_end - lc.q_begin, ctx->n_cu * per_cu);
-        max_blocks = std::max(max_blocks, c.blocks);
+        c.capacity = ctx->n_cu * per_cu;
+        c.blocks = std::min<int>(lc.q_end - lc.q_begin, c.capacity);
+        max_blocks = std::max(max_blocks, c.capacity);
         ctx->classes.push_back(c);
     }
     int capG_s = K.capG, capR = K.capR, capP = K.capP, capC = K.capC;
@@ -389,14 +400,29 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.filled_len = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)str_total, &p))) return rc; db.str = (char *)p;
-    if ((rc = dev_alloc(ctx, 64, &p))) return rc; db.queue_head = (int32_t *)p;
+    if ((rc = dev_alloc(ctx, 64 * (ctx->classes.size() + 1), &p))) return rc; db.queue_head = (int32_t *)p;
     if ((rc = dev_alloc(ctx, 256, &p))) return rc; db.counters = (unsigned long long *)p;
-    if ((rc = dev_alloc(ctx, (size_t)stride * max_blocks, &p))) return rc; db.scratch = (uint8_t *)p;
+    size_t total_blocks = 0;
+    for (const fig_ctx::Cls &c : ctx->classes) total_blocks += (size_t)c.capacity;
+    (void)max_blocks;
+    if ((rc = dev_alloc(ctx, (size_t)stride * std::max<size_t>(total_blocks, 1), &p))) return rc; db.scratch = (uint8_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)K.persist_total + 256, &p))) return rc; db.persist = (uint8_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)std::max<int64_t>(ng, 1) * 16, &p))) return rc; db.gapctl = (int32_t *)p;
-    ctx->nslots = K.nslots; ctx->sched_cap = (size_t)std::max<int64_t>(ng, 1) * 4 * (size_t)(K.nslots + 1);
-    if ((rc = dev_alloc(ctx, ctx->sched_cap * 4, &p))) return rc; ctx->d_items = (int *)p;
-    if ((rc = dev_alloc(ctx, ctx->sched_cap * 4, &p))) return rc; ctx->d_entries = (int *)p;
+    ctx->nslots = K.nslots;
+    {   size_t blk = 0;
+        for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
+            const fig_ctx::Cls &c = ctx->classes[ci];
+            FigLane ln;
+            if (hipStreamCreate(&ln.stream) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) return FIG_EHIP;
+            ctx->lanes.push_back(ln);
+            FigLane &l = ctx->lanes.back();
+            l.queue_head = db.queue_head + 16 * (ci + 1);
+            l.scratch = db.scratch + (size_t)stride * blk; blk += (size_t)c.capacity;
+            l.cap = (size_t)std::max(c.c.q_end - c.c.q_begin, 1) * 4 * (size_t)(K.nslots + 1);
+            if ((rc = dev_alloc(ctx, l.cap * 4, &p))) return rc; l.d_items = (int *)p;
+            if ((rc = dev_alloc(ctx, l.cap * 4, &p))) return rc; l.d_entries = (int *)p;
+        }
+    }
     db.scratch_stride = stride;
     db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC; db.capW = K.capW; db.capE = K.capE;
     db.n_ureads = ctx->n_ureads;
@@ -419,61 +445,69 @@ static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
 
 // kind: 0 sequential fill, 1 begin, 2 eval (items), 3 end (list)
 template <bool LDS_TAB, int NT>
-static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, int kind, int blocks, const void *list, int n) {
+static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n) {
     FigKernArgs A = kargs_of(c);
     hipError_t e = hipSuccess;
     if (kind == 0) {
         auto k = fig_fill_kernel<LDS_TAB, NT>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A);
     } else if (kind == 1) {
         auto k = fig_begin_kernel<LDS_TAB, NT>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A);
     } else if (kind == 2) {
         auto k = fig_eval_kernel<LDS_TAB, NT>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A, (const int4 *)list, n);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A, (const int4 *)list, n);
     } else {
         auto k = fig_end_kernel<LDS_TAB, NT>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
         if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, ctx->stream, ctx->dm, ctx->db, A, (const int *)list, n);
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A, (const int *)list, n);
     }
     return hipGetLastError();
 }
 
-static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, int kind, int blocks, const void *list, int n) {
-    if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, kind, blocks, list, n) : launch_kind<true, 512>(ctx, c, kind, blocks, list, n);
-    return launch_kind<false, 512>(ctx, c, kind, blocks, list, n);
+static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n) {
+    if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, db, stream, kind, blocks, list, n) : launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n);
+    return launch_kind<false, 512>(ctx, c, db, stream, kind, blocks, list, n);
 }
 
 // Candidate-parallel scheduling of one class (see fig_engine_sched.h).  Host-driven rounds: begin -> {eval chunk,
 // replay}* -> end.  Returns the number of kernel launches, or -1 on a HIP error (ctx->last_hip set).
-static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c) {
-    FigDevBatch &db = ctx->db;
+static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane &ln) {
+    FigDevBatch db = ctx->db;
+    db.queue_head = ln.queue_head; db.scratch = ln.scratch;
+    hipStream_t stream = ln.stream;
+    hipSetDevice(ctx->device);
     const int n_cls = c.c.q_end - c.c.q_begin;
     int nl = 0;
     hipError_t e;
     auto fail = [&](hipError_t er) { ctx->last_hip = (int)er; return -1; };
-    hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
-    if ((e = launch_any(ctx, c, 1, c.blocks, nullptr, 0)) != hipSuccess) return fail(e);
+    hipMemsetAsync(db.queue_head, 0, 4, stream);
+    if ((e = launch_any(ctx, c, db, stream, 1, std::min(std::max(1, c.capacity), n_cls), nullptr, 0)) != hipSuccess) return fail(e);
     nl++;
     std::vector<int32_t> ctl((size_t)ctx->n_gaps * 4);
     std::vector<int> ids(ctx->h_order.begin() + c.c.q_begin, ctx->h_order.begin() + c.c.q_end);   // cost-sorted
     std::vector<int> items, entries, endlist;
     const int slots_cap = ctx->nslots;
-    const int capacity = std::max(1, c.blocks);
+    const int capacity = std::max(1, c.capacity);      // workgroups the device holds for this class (not capped by the gap count)
+    const bool log = getenv("FIG_SCHED_LOG") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0;
     while (true) {
-        if ((e = hipMemcpyAsync(ctl.data(), db.gapctl, ctl.size() * 4, hipMemcpyDeviceToHost, ctx->stream)) != hipSuccess) return fail(e);
-        if ((e = hipStreamSynchronize(ctx->stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(ctl.data(), db.gapctl, ctl.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
         int n_active = 0;
         for (int g : ids) if (ctl[(size_t)g * 4] == 1) n_active++;
+        if (log) { double t = now(); fprintf(stderr, "[figsched] capG=%d round %d: active=%d chunk=%d items=%d blocks=%d  %.1f ms\n", c.c.capG, round, last_active, last_chunk, last_items, capacity, t - t_prev); t_prev = t; }
+        round++;
         if (n_active == 0) break;
-        int chunk = (4 * capacity + n_active - 1) / n_active;
+        int chunk = (8 * capacity + n_active - 1) / n_active;
         chunk = std::max(2, std::min(chunk, slots_cap));
         items.clear(); entries.clear();
         for (int g : ids) {
@@ -483,29 +517,29 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c) {
             if (n <= 0) { n = 0; }
             entries.push_back(g); entries.push_back(n); entries.push_back(0); entries.push_back(0);
         }
-        // items ordered slot-major so that the first candidates of every gap are evaluated first
-        for (int k = 0; k < chunk; k++)
-            for (size_t q = 0; q < entries.size(); q += 4)
-                if (k < entries[q + 1]) { int g = entries[q]; items.push_back(g); items.push_back(ctl[(size_t)g * 4 + 1] + k); items.push_back(k); items.push_back(0); }
-        if (ctx->sched_cap < items.size() || ctx->sched_cap < entries.size()) return fail(hipErrorOutOfMemory);
+        // items gap-major in descending-cost gap order (longest processing time first keeps the round's tail short)
+        for (size_t q = 0; q < entries.size(); q += 4)
+            for (int k = entries[q + 1] - 1; k >= 0; k--) { int g = entries[q]; items.push_back(g); items.push_back(ctl[(size_t)g * 4 + 1] + k); items.push_back(k); items.push_back(0); }
+        if (ln.cap < items.size() || ln.cap < entries.size()) return fail(hipErrorOutOfMemory);
         int n_items = (int)(items.size() / 4), n_ent = (int)(entries.size() / 4);
+        last_items = n_items; last_active = n_active; last_chunk = chunk;
         if (n_items > 0) {
-            if ((e = hipMemcpyAsync(ctx->d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
-            hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
-            if ((e = launch_any(ctx, c, 2, std::min(capacity, n_items), ctx->d_items, n_items)) != hipSuccess) return fail(e);
+            if ((e = hipMemcpyAsync(ln.d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+            hipMemsetAsync(db.queue_head, 0, 4, stream);
+            if ((e = launch_any(ctx, c, db, stream, 2, std::min(capacity, n_items), ln.d_items, n_items)) != hipSuccess) return fail(e);
             nl++;
         }
-        if ((e = hipMemcpyAsync(ctx->d_entries, entries.data(), entries.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
-        hipLaunchKernelGGL(fig_replay_kernel, dim3(n_ent), dim3(64), sizeof(FigState) + 64, ctx->stream, ctx->dm, ctx->db, (const int4 *)ctx->d_entries, n_ent);
+        if ((e = hipMemcpyAsync(ln.d_entries, entries.data(), entries.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        hipLaunchKernelGGL(fig_replay_kernel, dim3(n_ent), dim3(64), sizeof(FigState) + 64, stream, ctx->dm, db, (const int4 *)ln.d_entries, n_ent);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
         nl++;
     }
     endlist.clear();
     for (int g : ids) if (ctl[(size_t)g * 4] == 2) endlist.push_back(g);
     if (!endlist.empty()) {
-        if ((e = hipMemcpyAsync(ctx->d_items, endlist.data(), endlist.size() * 4, hipMemcpyHostToDevice, ctx->stream)) != hipSuccess) return fail(e);
-        hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
-        if ((e = launch_any(ctx, c, 3, std::min(capacity, (int)endlist.size()), ctx->d_items, (int)endlist.size())) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(ln.d_items, endlist.data(), endlist.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        hipMemsetAsync(db.queue_head, 0, 4, stream);
+        if ((e = launch_any(ctx, c, db, stream, 3, std::min(capacity, (int)endlist.size()), ln.d_items, (int)endlist.size())) != hipSuccess) return fail(e);
         nl++;
     }
     (void)n_cls;
@@ -542,22 +576,38 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     }
     hipMemsetAsync(db.counters, 0, 256, ctx->stream);
     hipMemsetAsync(db.str, 'N', (size_t)ctx->str_total, ctx->stream);
+    hipMemsetAsync(db.gapctl, 0, (size_t)std::max<int64_t>(ng, 1) * 16, ctx->stream);
     hipEventRecord(ctx->ev0, ctx->stream);
     int nl = 0;
     const char *sched = getenv("FIG_SCHED");
     const bool seq = sched && strcmp(sched, "seq") == 0;
-    hipMemsetAsync(db.gapctl, 0, (size_t)std::max<int64_t>(ng, 1) * 16, ctx->stream);
-    for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
-        const fig_ctx::Cls &c = ctx->classes[ci];
-        if (seq) {
+    if (seq) {
+        for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
+            const fig_ctx::Cls &c = ctx->classes[ci];
             hipMemsetAsync(db.queue_head, 0, 4, ctx->stream);
-            hipError_t e = launch_any(ctx, c, 0, c.blocks, nullptr, 0);
+            hipError_t e = launch_any(ctx, c, db, ctx->stream, 0, c.blocks, nullptr, 0);
             if (e != hipSuccess) { ctx->last_hip = (int)e; tfree(); return FIG_EHIP; }
             nl++;
+        }
+    } else {
+        // one host thread + stream per class; every lane starts after ev0 and the main stream joins them before ev1
+        const size_t nc = ctx->classes.size();
+        std::vector<int> rcs(nc, 0);
+        ctx->db = db;
+        for (size_t ci = 0; ci < nc; ci++) hipStreamWaitEvent(ctx->lanes[ci].stream, ctx->ev0, 0);
+        const char *ser = getenv("FIG_LANES");
+        if (nc <= 1 || (ser && strcmp(ser, "serial") == 0)) {
+            for (size_t ci = 0; ci < nc; ci++) rcs[ci] = run_class_parallel(ctx, ctx->classes[ci], ctx->lanes[ci]);
         } else {
-            int r = run_class_parallel(ctx, c);
-            if (r < 0) { tfree(); return FIG_EHIP; }
-            nl += r;
+            std::vector<std::thread> th;
+            for (size_t ci = 0; ci < nc; ci++) th.emplace_back([&, ci] { rcs[ci] = run_class_parallel(ctx, ctx->classes[ci], ctx->lanes[ci]); });
+            for (auto &t : th) t.join();
+        }
+        for (size_t ci = 0; ci < nc; ci++) {
+            if (rcs[ci] < 0) { hipDeviceSynchronize(); tfree(); return FIG_EHIP; }
+            nl += rcs[ci];
+            hipEventRecord(ctx->lanes[ci].done, ctx->lanes[ci].stream);
+            hipStreamWaitEvent(ctx->stream, ctx->lanes[ci].done, 0);
         }
     }
     hipEventRecord(ctx->ev1, ctx->stream);
@@ -594,6 +644,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     { const char *nm[11] = {"E.phaseA", "E.phaseB", "M.chains", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0"};
       for (int i = 0; i < 11; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
 #endif
+    if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);
     ctx->stats.place_calls = (int64_t)cnt[0];
     ctx->stats.alg_flops = (double)cnt[1];
     // compact strings

@@ -383,7 +383,7 @@ FIG_D void fig_spec_eval(FigEng &E, const FigScr &work, const FigPersist &P, int
         unsigned char *pv = fig_slot_prev(P, slot, capGg);
         for (int x = E.tid; x < S.prev_len; x += E.nt) pv[x] = E.scr.prev[x];
     }
-    if (E.flops != flops0) fig_atomic_add_u64(&fig_slot_hdr(P, slot)->flops, E.flops - flops0);
+    if (E.flops != flops0) { fig_atomic_add_u64(&fig_slot_hdr(P, slot)->flops, E.flops - flops0); fig_atomic_add_u64(&E.B->counters[2], E.flops - flops0); }
     E.flops = flops0;                             // speculative work is credited by the replay, and only if it is consumed
     FIG_SYNC();
 }
