@@ -507,14 +507,22 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane
         if (log) { double t = now(); fprintf(stderr, "[figsched] capG=%d round %d: active=%d chunk=%d items=%d blocks=%d  %.1f ms\n", c.c.capG, round, last_active, last_chunk, last_items, capacity, t - t_prev); t_prev = t; }
         round++;
         if (n_active == 0) break;
-        int chunk = (8 * capacity + n_active - 1) / n_active;
-        chunk = std::max(2, std::min(chunk, slots_cap));
+        // Candidates per gap this round: proportional to the candidates the gap still has, so that all gaps of the class
+        // finish in about the same round and every round carries ~8 items per resident workgroup.  A gap that stops
+        // early discards at most chunk-1 evaluations.
+        long long rem_total = 0;
+        for (int g : ids) if (ctl[(size_t)g * 4] == 1) rem_total += std::max(0, ctl[(size_t)g * 4 + 2] - ctl[(size_t)g * 4 + 1]);
+        const double share = rem_total > 0 ? (8.0 * capacity) / (double)rem_total : 1.0;
+        int chunk = 0;
         items.clear(); entries.clear();
         for (int g : ids) {
             if (ctl[(size_t)g * 4] != 1) continue;
             int j = ctl[(size_t)g * 4 + 1], range = ctl[(size_t)g * 4 + 2];
-            int n = std::min(chunk, range - j);
+            int want = (int)std::ceil((range - j) * share);
+            want = std::max(2, std::min(want, slots_cap));
+            int n = std::min(want, range - j);
             if (n <= 0) { n = 0; }
+            chunk = std::max(chunk, n);
             entries.push_back(g); entries.push_back(n); entries.push_back(0); entries.push_back(0);
         }
         // items gap-major in descending-cost gap order (longest processing time first keeps the round's tail short)

@@ -74,7 +74,7 @@ struct FigPacked {
     std::vector<FigLaunchClass> classes;
     int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0, capE = 0;
     int64_t str_total = 0, n_gaps = 0, persist_total = 0;
-    int nslots = 32;
+    int nslots = 64;                  // speculative candidate slots per gap (fig_engine_sched.h)
     int64_t packed_bytes() const {
         return (int64_t)(packed.size() * 4 + flank.size() + gaps.size() * sizeof(FigDevGap) + qual.size() +
                          (u_pos.size() * 3 + p_pos.size() * 5) * 4 + (u_woff.size() + p_woff.size() + p_qoff.size()) * 8);
