@@ -47,7 +47,8 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.S = (FigState *)(fig_lds + off);
     unsigned char *bp = (unsigned char *)(E.S + 1);
     E.gs = bp; bp += ((A.capGl + 7) & ~7);
-    E.rb = bp;
+    E.rb = bp; bp += ((FIG_MAX_READLEN + 8 + 15) & ~15);
+    E.plb = (uint32_t *)bp; E.off_plb = (int)((double *)bp - fig_lds);
     E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
 }
 
@@ -133,7 +134,7 @@ __global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBat
     memset(&work, 0, sizeof(work));
     E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
     E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
-    E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.pq_lds = 0; E.w_lds = 0;
+    E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.plb = nullptr; E.off_plb = 0; E.pq_lds = 0; E.w_lds = 0;
     E.off_pq = E.off_q4 = E.off_w = 0;
     E.S = (FigState *)fig_lds;
     int4 en = entries[blockIdx.x];
@@ -649,8 +650,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->stats.d2h_ms = ms;
 #ifdef FIG_PROF
-    { const char *nm[11] = {"E.phaseA", "E.phaseB", "M.chains", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0"};
-      for (int i = 0; i < 11; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
+    { const char *nm[14] = {"A.wait.w0", "B.wait.w0", "M.wait.w0", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0", "A.work.w0", "B.work.w0", "M.work.w0"};
+      for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
 #endif
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);
     ctx->stats.place_calls = (int64_t)cnt[0];

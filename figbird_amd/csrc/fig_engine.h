@@ -57,6 +57,8 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { ato
 #endif
 
 #define FIG_NOPOS 0x7fffffff
+#define FIG_PLB_TEAMS 8
+#define FIG_PLB_BYTES (FIG_PLB_TEAMS * 64 * 4)
 
 // Optional phase timers (diagnostic build only: -DFIG_PROF).  Lane 0 of each workgroup adds s_memtime
 // deltas to B.counters[8+slot]; never enabled in the shipped library.
@@ -230,6 +232,7 @@ struct FigEng {
     FigPQ *pq; double *q4;           // generic pointers (LDS or scratch)
     int ncolE, xoff;
     int off_pq, off_q4, off_w;       // offsets (in doubles) from fig_lds when the table / weights live in LDS
+    int off_plb;                     // offset (in doubles) of plb from fig_lds (always LDS)
     int pq_lds, w_lds;
     double *wbuf;                    // [nteams][Wcap]
     int Wcap, nteams;
@@ -237,6 +240,7 @@ struct FigEng {
     const double *kt_fwd, *kt_rev;   // {1-e[k], e[k]} pairs, forward and reversed (index (L-len)+j), for scalar loads
     const double *mt_fwd, *mt_rev;   // {1-e-ins-del, e[k]} pairs for the MLE pass
     unsigned char *rb;               // staged read codes [FIG_MAX_READLEN + 8]
+    uint32_t *plb;                   // per-team staged position lists of the chunk's reads [FIG_PLB_TEAMS][64] (LDS)
     unsigned char *gs;               // consensus codes of the gap columns for the MLE pass [capG]
     int capG;
     unsigned long long flops;        // per-lane algorithmic flop count

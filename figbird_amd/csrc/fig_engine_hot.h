@@ -78,6 +78,17 @@ template <bool LDS> FIG_D const double *fig_q4_ptr(const FigEng &E) { return LDS
 template <bool LDS> FIG_D double *fig_w_ptr(const FigEng &E) { return LDS ? (double *)(fig_lds + fig_u(E.off_w)) : fig_uptr(E.wbuf); }
 template <bool LDS> FIG_D double *fig_c_ptr(const FigEng &E) { return LDS ? (double *)(fig_lds + fig_u(E.off_pq)) : (double *)fig_uptr(E.pq); }
 
+// volatile keeps the column-pass loads as single ds_read_b64 (256 B/clk); merged ds_read2st64_b64 runs at half that rate
+#ifdef FIG_EMU
+#define FIG_LDV(p) (*(p))
+#else
+template <bool LDS> FIG_D double fig_ldv(const double *p) {
+    if (LDS) return *(const volatile __attribute__((address_space(3))) double *)p;
+    return *p;
+}
+#define FIG_LDV(p) fig_ldv<LDS>(p)
+#endif
+
 // base j of a packed read through scalar loads
 FIG_D int fig_sbase(fig_cu32p pk, int nw2, int j) {
     uint32_t w = pk[j >> 4], m = pk[nw2 + (j >> 5)];
@@ -363,14 +374,20 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid;
     const int team = wave / T, wit = wave - team * T;
     const bool clipped = left < xoff;              // some placements start left of the window (gap near the contig start)
-    // Column pass work units = (base c in ACGT, 64-column tile): `nslots` of them, dealt round-robin to the waves;
-    // a lane keeps ONE accumulator per unit of its wave in registers for the whole E-step (CPL = units per wave).
-    // Reads with N bases add their N positions straight into countsGap[4] (lane = column, reads in order).
+    // Column pass: wave w owns base c = w & 3 and CPL consecutive 64-column tiles starting at tile (w >> 2) * CPL,
+    // one register accumulator per tile for the whole E-step.  All tiles of a wave walk the same position list
+    // (that base's positions in the read, four per staged dword), so the list decode is shared and the CPL add
+    // chains are independent.  Reads with N bases add their N positions straight into countsGap[4].
     // CPL == 0: generic fallback (very long gaps, and the one-lane CPU emulation): accumulate in E.scr.cnt.
     double acc[CPL > 0 ? CPL : 1];
 #pragma unroll
     for (int m = 0; m < (CPL > 0 ? CPL : 1); m++) acc[m] = 0;
-    const int ntiles = (G + U.wsz - 1) / U.wsz, nslots = 4 * ntiles;
+    const int pb_c = wave & 3, pb_x0 = (wave >> 2) * CPL * U.wsz + lane;       // this wave's base and first column
+#ifndef FIG_EMU
+    uint32_t *plb = (uint32_t *)(fig_lds + fig_u(E.off_plb));
+#else
+    uint32_t *plb = E.plb;
+#endif
     FIG_SYNC();                                       // placeReads zeroed countsGap already (:3050-3056)
 
     FIG_T0(E);
@@ -384,6 +401,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             if (wit == 0 && lane == 0) { S.tm_lo[team] = w.lo; S.tm_hi[team] = w.hi; S.tm_len[team] = rs.len; }
             fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
             int nw2 = (rs.len + 15) >> 4;
+            // stage {counts, position lists} of this read for the column pass: one dword per lane, stored below
+            uint32_t plv = 0;
+            if (CPL > 0 && wit == 0) { const int ndw = 2 + ((rs.len + 3) >> 2) + 4; if (lane < ndw) plv = pk[nw2 + ((rs.len + 31) >> 5) + lane]; }
             fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
             // weight row covers every placement offset o in [-(L-1), G-1] at index o+(L-1); offsets outside the
             // insert-size window hold 0.0 so that the column pass needs no window test (x + 0.0 == x exactly)
@@ -423,7 +443,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             E.flops += 4ULL * nplace * (unsigned long long)rs.len;
             best = fig_wave_best(E, best);
             if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
+            if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;
         }
+        FIG_TICK(E, 11);
         FIG_SYNC();
         FIG_TICK(E, 0);
         // ---- per-read bookkeeping (:3680-3688)
@@ -452,56 +474,77 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 }
                 continue;
             }
-            const uint32_t cw0 = pk[nw2 + nwm], cw1 = pk[nw2 + nwm + 1];
-            const int nb[4] = {(int)(cw0 & 255), (int)((cw0 >> 8) & 255), (int)((cw0 >> 16) & 255), (int)(cw0 >> 24)};
-            const int n4 = (int)(cw1 & 255);
-            const int ob4[4] = {0, nb[0], nb[0] + nb[1], nb[0] + nb[1] + nb[2]};
-#ifdef FIG_EMU
-            const unsigned char *pl = (const unsigned char *)(pk + nw2 + nwm + 2);
-#else
-            typedef const unsigned char __attribute__((address_space(4))) *fig_cu8p_;
-            fig_cu8p_ pl = (fig_cu8p_)(pk + nw2 + nwm + 2);
-#endif
+#ifndef FIG_EMU
+            if (CPL > 0) {
+                const uint32_t plv = plb[t * 64 + lane];
+                const uint32_t cw0 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 0), cw1 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 1);
+                const int nA = (int)(cw0 & 255), nC = (int)((cw0 >> 8) & 255), nG = (int)((cw0 >> 16) & 255), nT = (int)(cw0 >> 24);
+                const int n4 = (int)(cw1 & 255);
+                const int dC = 2 + ((nA + 3) >> 2), dG = dC + ((nC + 3) >> 2), dT = dG + ((nG + 3) >> 2), d4 = dT + ((nT + 3) >> 2);
+                const int n = pb_c == 0 ? nA : pb_c == 1 ? nC : pb_c == 2 ? nG : nT;
+                const int d0 = pb_c == 0 ? 2 : pb_c == 1 ? dC : pb_c == 2 ? dG : dT;
+                // tile i of this wave reads wl[i * 64 - j]: constant offsets from one per-position address
+                const double *wl = wrow + pb_x0;
+                int k4 = 0;
+                for (; k4 + 1 <= (n >> 2); k4++) {
+                    const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
+                    const double *p0 = wl - (int)(s4 & 255), *p1 = wl - (int)((s4 >> 8) & 255), *p2 = wl - (int)((s4 >> 16) & 255), *p3 = wl - (int)(s4 >> 24);
+                    if (CPL <= 4) {
+                        double w0[CPL > 0 ? CPL : 1], w1[CPL > 0 ? CPL : 1], w2[CPL > 0 ? CPL : 1], w3[CPL > 0 ? CPL : 1];
 #pragma unroll
-            for (int m = 0; m < CPL; m++) {
-                const int sl = wave + m * U.nw;
-                if (sl < nslots) {
-                    const int c = sl / ntiles, tile = sl - c * ntiles;
-                    const int x = tile * U.wsz + lane;
-                    const double *wx = wrow + (x < G ? x : 0);
-                    const int n = nb[c], o0 = ob4[c];
-                    double a = acc[m];
-                    int k = 0;
-                    for (; k + 4 <= n; k += 4) {               // 4 loads in flight, then the 4 ordered adds
-                        const int j0 = pl[o0 + k], j1 = pl[o0 + k + 1], j2 = pl[o0 + k + 2], j3 = pl[o0 + k + 3];
-                        const double w0 = wx[-j0], w1 = wx[-j1], w2 = wx[-j2], w3 = wx[-j3];
-                        a += w0; a += w1; a += w2; a += w3;
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p0 + i * 64); w1[i] = FIG_LDV(p1 + i * 64); w2[i] = FIG_LDV(p2 + i * 64); w3[i] = FIG_LDV(p3 + i * 64); }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w0[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w1[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w2[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w3[i];
+                    } else {
+                        double w0[CPL > 0 ? CPL : 1], w1[CPL > 0 ? CPL : 1];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p0 + i * 64); w1[i] = FIG_LDV(p1 + i * 64); }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w0[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p2 + i * 64); acc[i] += w1[i]; }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w1[i] = FIG_LDV(p3 + i * 64); acc[i] += w0[i]; }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w1[i];
                     }
-                    for (; k < n; k++) a += wx[-(int)pl[o0 + k]];
-                    acc[m] = a;
+                }
+                if (n & 3) {
+                    uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
+                    for (int q = 0; q < (n & 3); q++, s4 >>= 8) {
+                        const double *p0 = wl - (int)(s4 & 255);
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += FIG_LDV(p0 + i * 64);
+                    }
+                }
+                if (n4 > 0) {
+                    for (int x = tid; x < G; x += U.nt) {
+                        double a = E.scr.cnt[4 * cg + x];
+                        for (int k = 0; k < n4; k++) {
+                            const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d4 + (k >> 2));
+                            a += wrow[x - (int)((s4 >> ((k & 3) * 8)) & 255)];
+                        }
+                        E.scr.cnt[4 * cg + x] = a;
+                    }
                 }
             }
-            if (n4 > 0) {
-                const int o4 = ob4[3] + nb[3];
-                for (int x = tid; x < G; x += U.nt) {
-                    double a = E.scr.cnt[4 * cg + x];
-                    for (int k = 0; k < n4; k++) a += wrow[x - (int)pl[o4 + k]];
-                    E.scr.cnt[4 * cg + x] = a;
-                }
-            }
+#endif
         }
+        FIG_TICK(E, 12);
         FIG_SYNC();
         FIG_TICK(E, 1);
     }
     if (CPL > 0) {
 #pragma unroll
-        for (int m = 0; m < CPL; m++) {
-            const int sl = wave + m * U.nw;
-            if (sl < nslots) {
-                const int c = sl / ntiles, tile = sl - c * ntiles;
-                const int x = tile * U.wsz + lane;
-                if (x < G) E.scr.cnt[c * cg + x] = acc[m];
-            }
+        for (int i = 0; i < CPL; i++) {
+            const int x = pb_x0 + i * U.wsz;
+            if (x < G) E.scr.cnt[pb_c * cg + x] = acc[i];
         }
     }
     FIG_SYNC();
@@ -509,15 +552,27 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
 
 template <bool LDS>
 FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
+#ifdef FIG_EMU
+    fig_hot_estep<LDS, 0>(E, gapoffset);
+#else
     const int ntiles = (E.S->G + E.wsz - 1) / E.wsz;
-    const int cpl = (4 * ntiles + E.nw - 1) / E.nw;      // column-pass units per wave
-    if (cpl <= 1) fig_hot_estep<LDS, 1>(E, gapoffset);
-    else if (cpl == 2) fig_hot_estep<LDS, 2>(E, gapoffset);
-    else if (cpl <= 4) fig_hot_estep<LDS, 4>(E, gapoffset);
-    else if (cpl <= 6) fig_hot_estep<LDS, 6>(E, gapoffset);
-    else if (cpl <= 10) fig_hot_estep<LDS, 10>(E, gapoffset);
-    else if (cpl <= 16) fig_hot_estep<LDS, 16>(E, gapoffset);
-    else fig_hot_estep<LDS, 0>(E, gapoffset);
+    const int nsub = E.nw >> 2;                          // waves per base (workgroups are 4 or 8 waves)
+    const int cpl = nsub > 0 ? (ntiles + nsub - 1) / nsub : 99;      // tiles per wave
+    switch (cpl) {
+        case 1: fig_hot_estep<LDS, 1>(E, gapoffset); break;
+        case 2: fig_hot_estep<LDS, 2>(E, gapoffset); break;
+        case 3: fig_hot_estep<LDS, 3>(E, gapoffset); break;
+        case 4: fig_hot_estep<LDS, 4>(E, gapoffset); break;
+        case 5: fig_hot_estep<LDS, 5>(E, gapoffset); break;
+        case 6: fig_hot_estep<LDS, 6>(E, gapoffset); break;
+        case 7: fig_hot_estep<LDS, 7>(E, gapoffset); break;
+        case 8: fig_hot_estep<LDS, 8>(E, gapoffset); break;
+        case 9: case 10: fig_hot_estep<LDS, 10>(E, gapoffset); break;
+        case 11: case 12: fig_hot_estep<LDS, 12>(E, gapoffset); break;
+        case 13: case 14: case 15: case 16: fig_hot_estep<LDS, 16>(E, gapoffset); break;
+        default: fig_hot_estep<LDS, 0>(E, gapoffset); break;
+    }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------
@@ -597,6 +652,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             best = fig_wave_best(E, best);
             if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
         }
+        FIG_TICK(E, 13);
         FIG_SYNC();
         FIG_TICK(E, 2);
         // ---- the first wave of each team finishes its read: accept test + integer pile-up

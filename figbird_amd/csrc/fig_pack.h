@@ -44,7 +44,9 @@ static inline int code_of(char c) {
 //               [positions of A, then C, G, T, N bases, each list in DESCENDING order: ceil(len/4) words].
 // The position lists let the column-accumulation pass of the E-step run one branch-free add chain per base.
 static void pack_read(const char *s, int len, std::vector<uint32_t> &out) {
-    int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5, nwp = (len + 3) >> 2;
+    // record: 2-bit codes | N mask | {cntA,cntC,cntG,cntT},{cntN} | per-base position lists (descending j), each
+    // list padded to a dword boundary so that the column pass can take four positions from one register
+    int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5, nwp = ((len + 3) >> 2) + 4;
     size_t base = out.size();
     out.resize(base + nw2 + nwm + 2 + nwp, 0u);
     int cnt[5] = {0, 0, 0, 0, 0};
@@ -58,8 +60,10 @@ static void pack_read(const char *s, int len, std::vector<uint32_t> &out) {
     for (int c = 0; c < 5; c++) cb[c] = (uint8_t)cnt[c];
     uint8_t *pl = (uint8_t *)&out[base + nw2 + nwm + 2];
     int k = 0;
-    for (int c = 0; c < 5; c++)
+    for (int c = 0; c < 5; c++) {
         for (int j = len - 1; j >= 0; j--) if (code_of(s[j]) == c) pl[k++] = (uint8_t)j;
+        k = (k + 3) & ~3;
+    }
 }
 
 struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end; };
@@ -196,7 +200,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         c.Wcap = (c.capGl + m->max_read_length + 7) & ~7;
         c.nt = cd.nt;
         const size_t LDS_MAX = 160 * 1024 - 1024;
-        size_t fixed = state_bytes + (size_t)c.capGl + FIG_MAX_READLEN + 64;
+        size_t fixed = state_bytes + (size_t)c.capGl + FIG_MAX_READLEN + 64 + FIG_PLB_BYTES;
         int nw = c.nt / 64;
         c.lds_tab = false; c.nteams = nw;
         for (int nt_ = nw; nt_ >= 1; nt_ >>= 1) {
@@ -209,7 +213,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         c.q_end = (int)K.order.size();
         K.classes.push_back(c);
         K.capE = std::max(K.capE, c.ncolE);
-        K.capW = std::max(K.capW, c.nteams * c.Wcap);
+        K.capW = std::max(K.capW, c.nteams * c.Wcap + 1024);   // + slack: the column pass reads up to 2 tiles past a row's end
     }
     return FIG_OK;
 }

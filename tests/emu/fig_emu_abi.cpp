@@ -110,7 +110,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     for (const FigLaunchClass &c : K.classes) {
         // one emulated lane = one wave of width 1; the class's team count is kept so the chunking logic runs
         int nteams = 1;
-        std::vector<double> lds((size_t)(9LL * c.ncolE + (long long)nteams * c.Wcap) + (sizeof(FigState) + c.capGl + FIG_MAX_READLEN + 64) / 8 + 8, 0.0);
+        std::vector<double> lds((size_t)(9LL * c.ncolE + (long long)nteams * c.Wcap) + (sizeof(FigState) + c.capGl + FIG_MAX_READLEN + 64 + FIG_PLB_BYTES) / 8 + 8, 0.0);
         fig_lds = lds.data();
         FigEng E;
         E.tid = 0; E.nt = 1; E.lane = 0; E.wave = 0; E.nw = 1; E.wsz = 1;
@@ -122,7 +122,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
         E.S = (FigState *)(fig_lds + 9LL * c.ncolE + (long long)nteams * c.Wcap);
         unsigned char *bp = (unsigned char *)(E.S + 1);
-        E.gs = bp; bp += ((c.capGl + 7) & ~7); E.rb = bp;
+        E.gs = bp; bp += ((c.capGl + 7) & ~7); E.rb = bp; bp += ((FIG_MAX_READLEN + 8 + 15) & ~15); E.plb = (uint32_t *)bp; E.off_plb = 0;
         E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;
         FigScr work = E.scr;
         const char *sched = getenv("FIG_SCHED");
