@@ -588,10 +588,12 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int G = U.G, left = U.left, nU = U.nU, cg = U.cg, G0 = U.G0;
     const long long ub = U.ub;
     const int ncolE = U.ncolE, xoff = U.xoff;
-    int nteams = U.nteams; if (nteams > U.nw) nteams = U.nw;
-    const int T = U.nw / nteams;
+    // one read per wave: the MLE pass keeps no weight rows, and a wave that owns the whole read prunes every round
+    // but the hinted one with its own running maximum
+    const int nteams = U.nw;
+    const int T = 1;
     const int wave = fig_u(E.wave), lane = E.lane;
-    const int team = wave / T, wit = wave - team * T;
+    const int team = wave, wit = 0;
     const int ncl = mode == 0 ? S.ncols : (gl > cg ? cg : gl);
     for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = 0;
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
@@ -650,16 +652,11 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             }
             E.flops += nplace * (unsigned long long)rs.len;
             best = fig_wave_best(E, best);
-            if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
-        }
-        FIG_TICK(E, 13);
-        FIG_SYNC();
-        FIG_TICK(E, 2);
-        // ---- the first wave of each team finishes its read: accept test + integer pile-up
-        if (active && wit == 0) {
-            FigBest b; b.v = init; b.o = FIG_NOPOS;
-            for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[team * T + k]; y.o = S.wv_o[team * T + k]; b = fig_best_merge(b, y); }
-            int o = b.o == FIG_NOPOS ? -left : b.o;
+            // ---- the wave finishes its read (no workgroup barrier anywhere in this loop): accept test + integer pile-up
+            FigBest b;
+            { long long bits; memcpy(&bits, &best.v, 8); bits = fig_u64(bits); memcpy(&b.v, &bits, 8); b.o = fig_u(best.o); }
+            FIG_TICK(E, 13);
+            int of = b.o == FIG_NOPOS ? -left : b.o;
             if (lane == 0) E.scr.hint[r] = b.o;
             double mp = b.o == FIG_NOPOS ? init : b.v;
             double temp_log_val = -fig_log10(mp);
@@ -669,7 +666,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
                 int nw2 = (rs.len + 15) >> 4;
                 for (int j = lane; j < rs.len; j += U.wsz) {
-                    int x = o + j;
+                    int x = of + j;
                     if (x >= 0 && x < gl) fig_atomic_add_i32(&E.scr.nci[fig_sbase(pk, nw2, j) * cg + x], 1);
                 }
             }
@@ -680,32 +677,32 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                         E.scr.maxlv[r] = -temp_log_val;
                         fig_atomic_add_i32(&S.valid_count, 1);
                         E.scr.mark[r] = 1;
-                        E.scr.frp[r * 2] = o; E.scr.frp[r * 2 + 1] = rs.len;
-                        if (G == G0) { E.scr.org[r * 2] = o; E.scr.org[r * 2 + 1] = rs.len; }
+                        E.scr.frp[r * 2] = of; E.scr.frp[r * 2 + 1] = rs.len;
+                        if (G == G0) { E.scr.org[r * 2] = of; E.scr.org[r * 2 + 1] = rs.len; }
                         if (G0 <= 30) {
-                            int val = o + rs.len - G;
-                            if (o < 0 && val > 0) { if (-o > 3 && val > 3) fig_atomic_or_i32(&S.ucoverf, 1); }
-                            if (o < 0 && o + rs.len > 0) { if (-o > 3) fig_atomic_or_i32(&S.umaxleftf, 1); }
-                            if (o > 0 && o < G && val > 0) { if (val > 3) fig_atomic_or_i32(&S.umaxrightf, 1); }
+                            int val = of + rs.len - G;
+                            if (of < 0 && val > 0) { if (-of > 3 && val > 3) fig_atomic_or_i32(&S.ucoverf, 1); }
+                            if (of < 0 && of + rs.len > 0) { if (-of > 3) fig_atomic_or_i32(&S.umaxleftf, 1); }
+                            if (of > 0 && of < G && val > 0) { if (val > 3) fig_atomic_or_i32(&S.umaxrightf, 1); }
                         }
                     }
                 } else {
                     fig_atomic_add_i32(&S.fin_i[6], 1);                                   // totalCount
                     if (acc) {
-                        if (E.B->draw_pos) { E.B->draw_pos[ub + r] = o; E.B->draw_isz[ub + r] = w.tis0 + w.dir * o; }
-                        E.scr.fin[r * 2] = o; E.scr.fin[r * 2 + 1] = rs.len;
-                        if (o == 0) fig_atomic_or_i32(&S.fin_i[4], 1);                    // left_start_zero
-                        if (o + rs.len == G) fig_atomic_or_i32(&S.fin_i[5], 1);           // right_fin_glen
-                        if (o < 0 && o + rs.len > 0) { fig_atomic_or_i32(&S.fin_i[0], 1); fig_atomic_max_i32(&S.fin_i[2], -o); }
-                        int val = o + rs.len - G;
-                        if (o < G && val > 0) { fig_atomic_or_i32(&S.fin_i[1], 1); fig_atomic_max_i32(&S.fin_i[3], val); }
+                        if (E.B->draw_pos) { E.B->draw_pos[ub + r] = of; E.B->draw_isz[ub + r] = w.tis0 + w.dir * of; }
+                        E.scr.fin[r * 2] = of; E.scr.fin[r * 2 + 1] = rs.len;
+                        if (of == 0) fig_atomic_or_i32(&S.fin_i[4], 1);                    // left_start_zero
+                        if (of + rs.len == G) fig_atomic_or_i32(&S.fin_i[5], 1);           // right_fin_glen
+                        if (of < 0 && of + rs.len > 0) { fig_atomic_or_i32(&S.fin_i[0], 1); fig_atomic_max_i32(&S.fin_i[2], -of); }
+                        int val = of + rs.len - G;
+                        if (of < G && val > 0) { fig_atomic_or_i32(&S.fin_i[1], 1); fig_atomic_max_i32(&S.fin_i[3], val); }
                     } else fig_atomic_add_i32(&S.fin_i[7], 1);                            // discardedCount
                 }
             }
         }
-        FIG_SYNC();
         FIG_TICK(E, 3);
     }
+    FIG_SYNC();
 }
 
 #endif
