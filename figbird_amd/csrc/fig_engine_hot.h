@@ -222,27 +222,53 @@ FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, f
 // MLE pair chain with exact pruning.  Every factor is <= 1, so a partial product only shrinks: once both partial
 // products of every lane of the wave are below `bound` (a product some placement of this read has already
 // ACHIEVED), none of them can be the arg-max and the rest of the round is skipped.  Returns false if pruned.
+struct FigMBlk { double kk[16]; double va[8], vb[8]; };
+
+template <bool LDS>
+FIG_D void fig_mblk_load(FigMBlk &B, const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int bi, int xa, int xb) {
+    const int j0 = bi * 8;
+    const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
+    fig_cdp k2 = mt + 2 * j0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) B.kk[q] = k2[q];
+    const double *ca = C + xa + j0, *cb = C + xb + j0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; B.va[jj] = ca[r]; B.vb[jj] = cb[r]; }
+}
+FIG_D void fig_mblk_compute(const FigMBlk &B, double &qa, double &qb) {
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        const double fa = B.kk[2 * jj + 1] * B.va[jj], fb = B.kk[2 * jj + 1] * B.vb[jj];
+        qa *= (B.va[jj] < 0 ? B.kk[2 * jj] : fa);
+        qb *= (B.vb[jj] < 0 ? B.kk[2 * jj] : fb);
+    }
+}
+
+// Pruned MLE pair chain, software-pipelined like fig_hot_chain_e2.  Returns false as soon as no live lane of the
+// wave can still reach `bound` (all factors are <= 1, so partial products only shrink); the prefetched block is
+// then simply dropped.
 template <bool LDS>
 FIG_D bool fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
                              double bound, double &qa, double &qb) {
     const int nblk = len >> 3;
-    for (int bi = 0; bi < nblk; bi++) {
-        const int j0 = bi * 8;
-        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
-        fig_cdp k2 = mt + 2 * j0;
-        double kk[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) kk[q] = k2[q];
-        const double *ca = C + xa + j0, *cb = C + xb + j0;
-        double va[8], vb[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const double fa = kk[2 * jj + 1] * va[jj], fb = kk[2 * jj + 1] * vb[jj];
-            qa *= (va[jj] < 0 ? kk[2 * jj] : fa);
-            qb *= (vb[jj] < 0 ? kk[2 * jj] : fb);
+    if (nblk > 0) {
+        FigMBlk A, Bk;
+        fig_mblk_load<LDS>(A, C, ncolE, pk, mt, 0, xa, xb);
+        int bi = 0;
+        for (; bi + 2 <= nblk - 1; bi += 2) {
+            fig_mblk_load<LDS>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
+            fig_mblk_compute(A, qa, qb);
+            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+            fig_mblk_load<LDS>(A, C, ncolE, pk, mt, bi + 2, xa, xb);
+            fig_mblk_compute(Bk, qa, qb);
+            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
         }
+        if (bi + 1 <= nblk - 1) {
+            fig_mblk_load<LDS>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
+            fig_mblk_compute(A, qa, qb);
+            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+            fig_mblk_compute(Bk, qa, qb);
+        } else fig_mblk_compute(A, qa, qb);
         if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
     }
     for (int j = nblk * 8; j < len; j++) {
