@@ -29,7 +29,7 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.tid = threadIdx.x; E.nt = blockDim.x;
     E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
-    E.capG = A.capG; E.flops = 0;
+    E.capG = A.capG; E.flops = 0; E.wait_cycles = 0;
     E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
     fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &work);
@@ -64,6 +64,9 @@ template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
+#ifdef FIG_PROF
+    const unsigned long long _k0 = __builtin_readcyclecounter();
+#endif
     while (true) {
         if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
         __syncthreads();
@@ -75,6 +78,9 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
         fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
         fig_fill_gap<LDS_TAB>(E);
     }
+#ifdef FIG_PROF
+    if (E.lane == 0) { atomicAdd(&B.counters[30], E.wait_cycles); atomicAdd(&B.counters[31], (unsigned long long)__builtin_readcyclecounter() - _k0); }
+#endif
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
 }
 
@@ -133,7 +139,7 @@ __global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBat
     FigEng E; FigScr work;
     memset(&work, 0, sizeof(work));
     E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
-    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
+    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
     E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.plb = nullptr; E.off_plb = 0; E.pq_lds = 0; E.w_lds = 0;
     E.off_pq = E.off_q4 = E.off_w = 0;
     E.S = (FigState *)fig_lds;
@@ -651,7 +657,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     ctx->stats.d2h_ms = ms;
 #ifdef FIG_PROF
     { const char *nm[14] = {"A.wait.w0", "B.wait.w0", "M.wait.w0", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0", "A.work.w0", "B.work.w0", "M.work.w0"};
-      for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9); }
+      for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9);
+      fprintf(stderr, "[figprof] barrier wait %.3f of %.3f wave-Gcycles = %.1f %%\n", cnt[30] / 1e9, cnt[31] / 1e9, cnt[31] ? 100.0 * cnt[30] / cnt[31] : 0.0); }
 #endif
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);
     ctx->stats.place_calls = (int64_t)cnt[0];

@@ -44,7 +44,12 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { *p 
 #include <hip/hip_runtime.h>
 #define FIG_D __device__ static
 #define FIG_HD __host__ __device__ static
+#ifdef FIG_PROF
+// diagnostic build: every lane accumulates the cycles it spends in workgroup barriers (E must be in scope)
+#define FIG_SYNC() do { unsigned long long _bt = __builtin_readcyclecounter(); __syncthreads(); E.wait_cycles += __builtin_readcyclecounter() - _bt; } while (0)
+#else
 #define FIG_SYNC() __syncthreads()
+#endif
 FIG_D double fig_log10(double x) { return log10(x); }
 FIG_D double fig_log(double x) { return log(x); }
 FIG_D double fig_exp(double x) { return exp(x); }
@@ -62,7 +67,7 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { ato
 
 // Optional phase timers (diagnostic build only: -DFIG_PROF).  Lane 0 of each workgroup adds s_memtime
 // deltas to B.counters[8+slot]; never enabled in the shipped library.
-#if defined(FIG_PROF) && !defined(FIG_EMU)
+#if defined(FIG_PROF) && (FIG_PROF >= 2) && !defined(FIG_EMU)
 #define FIG_T0(E) unsigned long long _fig_t = ((E).tid == 0) ? __builtin_readcyclecounter() : 0ULL
 #define FIG_TICK(E, slot) do { if ((E).tid == 0) { unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&(E).B->counters[8 + (slot)], _n - _fig_t); _fig_t = _n; } } while (0)
 #else
@@ -244,6 +249,7 @@ struct FigEng {
     unsigned char *gs;               // consensus codes of the gap columns for the MLE pass [capG]
     int capG;
     unsigned long long flops;        // per-lane algorithmic flop count
+    unsigned long long wait_cycles;  // FIG_PROF only: cycles spent in workgroup barriers
 };
 
 // ---------------------------------------------------------------------------------------
