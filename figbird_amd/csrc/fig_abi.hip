@@ -23,7 +23,7 @@
 // ------------------------------------------------------------------------------------- kernel
 // LDS carve-up (doubles first so everything stays 8-byte aligned), LDS_TAB only:
 //   PQ[4][ncolE] (16 B each)  Q4[ncolE]  wbuf[nteams][Wcap]  | FigState  gs[capGl]  rb[FIG_MAX_READLEN+8]
-struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end; };
+struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel; };
 
 FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
     E.tid = threadIdx.x; E.nt = blockDim.x;
@@ -64,11 +64,12 @@ template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
 #ifdef FIG_PROF
     const unsigned long long _k0 = __builtin_readcyclecounter();
 #endif
     while (true) {
-        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
         int qi = A.q_begin + E.S->bc_i;
         __syncthreads();
@@ -89,8 +90,9 @@ template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_begin_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
     while (true) {
-        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
         int qi = A.q_begin + E.S->bc_i;
         __syncthreads();
@@ -118,8 +120,9 @@ template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_eval_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A, const int4 *items, int n_items) {
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
     while (true) {
-        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
         int qi = E.S->bc_i;
         __syncthreads();
@@ -155,8 +158,9 @@ template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_end_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A, const int *list, int n) {
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
     while (true) {
-        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head, 1);
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
         int qi = E.S->bc_i;
         __syncthreads();
@@ -183,7 +187,8 @@ struct DevBuf {
 // Per-class scheduling lane: the classes of a batch run concurrently, each on its own stream with its own work
 // queue head, scratch slabs and item buffers, so that the tail of one class's round is filled by the other
 // classes' workgroups.
-struct FigLane { hipStream_t stream = nullptr; hipEvent_t done = nullptr; int32_t *queue_head = nullptr; uint8_t *scratch = nullptr; int *d_items = nullptr, *d_entries = nullptr; size_t cap = 0; };
+struct FigLane { hipStream_t stream = nullptr; hipEvent_t done = nullptr; int32_t *queue_head = nullptr; uint8_t *scratch = nullptr; int *d_items = nullptr, *d_entries = nullptr; size_t cap = 0;
+                 int32_t *h_ctl = nullptr; int *h_items = nullptr, *h_entries = nullptr; int qsel = 0; };   // h_*: pinned, so the copies run on the DMA engines and never wait for a CU
 
 struct fig_ctx {
     int device = 0;
@@ -277,7 +282,7 @@ static void free_batch(fig_ctx *ctx) {
     ctx->bufs.clear();
     ctx->have_batch = false;
     ctx->classes.clear();
-    for (auto &l : ctx->lanes) { if (l.stream) hipStreamDestroy(l.stream); if (l.done) hipEventDestroy(l.done); }
+    for (auto &l : ctx->lanes) { if (l.stream) hipStreamDestroy(l.stream); if (l.done) hipEventDestroy(l.done); if (l.h_ctl) hipHostFree(l.h_ctl); if (l.h_items) hipHostFree(l.h_items); if (l.h_entries) hipHostFree(l.h_entries); }
     ctx->lanes.clear();
 }
 
@@ -428,12 +433,16 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
             l.cap = (size_t)std::max(c.c.q_end - c.c.q_begin, 1) * 4 * (size_t)(K.nslots + 1);
             if ((rc = dev_alloc(ctx, l.cap * 4, &p))) return rc; l.d_items = (int *)p;
             if ((rc = dev_alloc(ctx, l.cap * 4, &p))) return rc; l.d_entries = (int *)p;
+            if (hipHostMalloc((void **)&l.h_ctl, (size_t)std::max<int64_t>(ng, 1) * 16, hipHostMallocDefault) != hipSuccess) return FIG_ENOMEM;
+            if (hipHostMalloc((void **)&l.h_items, l.cap * 4, hipHostMallocDefault) != hipSuccess) return FIG_ENOMEM;
+            if (hipHostMalloc((void **)&l.h_entries, l.cap * 4, hipHostMallocDefault) != hipSuccess) return FIG_ENOMEM;
         }
     }
     db.scratch_stride = stride;
     db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC; db.capW = K.capW; db.capE = K.capE;
     db.n_ureads = ctx->n_ureads;
     FIG_HIP(hipMemsetAsync(db.counters, 0, 256, ctx->stream));
+    FIG_HIP(hipMemsetAsync(db.queue_head, 0, 64 * (ctx->classes.size() + 1), ctx->stream));
     hipEventRecord(ctx->ev1, ctx->stream);
     FIG_HIP(hipStreamSynchronize(ctx->stream));
     float ms = 0; hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
@@ -446,14 +455,15 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
 static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     FigKernArgs A;
     A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
-    A.q_begin = c.c.q_begin; A.q_end = c.c.q_end;
+    A.q_begin = c.c.q_begin; A.q_end = c.c.q_end; A.qsel = 0;
     return A;
 }
 
 // kind: 0 sequential fill, 1 begin, 2 eval (items), 3 end (list)
 template <bool LDS_TAB, int NT>
-static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n) {
+static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel) {
     FigKernArgs A = kargs_of(c);
+    A.qsel = qsel;
     hipError_t e = hipSuccess;
     if (kind == 0) {
         auto k = fig_fill_kernel<LDS_TAB, NT>;
@@ -479,14 +489,14 @@ static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevB
     return hipGetLastError();
 }
 
-static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n) {
-    if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, db, stream, kind, blocks, list, n) : launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n);
-    return launch_kind<false, 512>(ctx, c, db, stream, kind, blocks, list, n);
+static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel = 0) {
+    if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, db, stream, kind, blocks, list, n, qsel) : launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);
+    return launch_kind<false, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);
 }
 
 // Candidate-parallel scheduling of one class (see fig_engine_sched.h).  Host-driven rounds: begin -> {eval chunk,
 // replay}* -> end.  Returns the number of kernel launches, or -1 on a HIP error (ctx->last_hip set).
-static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane &ln) {
+static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) {
     FigDevBatch db = ctx->db;
     db.queue_head = ln.queue_head; db.scratch = ln.scratch;
     hipStream_t stream = ln.stream;
@@ -495,10 +505,12 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane
     int nl = 0;
     hipError_t e;
     auto fail = [&](hipError_t er) { ctx->last_hip = (int)er; return -1; };
-    hipMemsetAsync(db.queue_head, 0, 4, stream);
-    if ((e = launch_any(ctx, c, db, stream, 1, std::min(std::max(1, c.capacity), n_cls), nullptr, 0)) != hipSuccess) return fail(e);
+    // every persistent launch pops from one of the lane's two queue heads and zeroes the other for its successor
+    if ((e = launch_any(ctx, c, db, stream, 1, std::min(std::max(1, c.capacity), n_cls), nullptr, 0, ln.qsel)) != hipSuccess) return fail(e);
+    ln.qsel ^= 1;
     nl++;
-    std::vector<int32_t> ctl((size_t)ctx->n_gaps * 4);
+    int32_t *ctl = ln.h_ctl;
+    const size_t ctl_n = (size_t)ctx->n_gaps * 4;
     std::vector<int> ids(ctx->h_order.begin() + c.c.q_begin, ctx->h_order.begin() + c.c.q_end);   // cost-sorted
     std::vector<int> items, entries, endlist;
     const int slots_cap = ctx->nslots;
@@ -507,7 +519,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0;
     while (true) {
-        if ((e = hipMemcpyAsync(ctl.data(), db.gapctl, ctl.size() * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
+        if ((e = hipMemcpyAsync(ctl, db.gapctl, ctl_n * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
         int n_active = 0;
         for (int g : ids) if (ctl[(size_t)g * 4] == 1) n_active++;
@@ -539,12 +551,14 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane
         int n_items = (int)(items.size() / 4), n_ent = (int)(entries.size() / 4);
         last_items = n_items; last_active = n_active; last_chunk = chunk;
         if (n_items > 0) {
-            if ((e = hipMemcpyAsync(ln.d_items, items.data(), items.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
-            hipMemsetAsync(db.queue_head, 0, 4, stream);
-            if ((e = launch_any(ctx, c, db, stream, 2, std::min(capacity, n_items), ln.d_items, n_items)) != hipSuccess) return fail(e);
+            memcpy(ln.h_items, items.data(), items.size() * 4);
+            if ((e = hipMemcpyAsync(ln.d_items, ln.h_items, items.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+            if ((e = launch_any(ctx, c, db, stream, 2, std::min(capacity, n_items), ln.d_items, n_items, ln.qsel)) != hipSuccess) return fail(e);
+            ln.qsel ^= 1;
             nl++;
         }
-        if ((e = hipMemcpyAsync(ln.d_entries, entries.data(), entries.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        memcpy(ln.h_entries, entries.data(), entries.size() * 4);
+        if ((e = hipMemcpyAsync(ln.d_entries, ln.h_entries, entries.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
         hipLaunchKernelGGL(fig_replay_kernel, dim3(n_ent), dim3(64), sizeof(FigState) + 64, stream, ctx->dm, db, (const int4 *)ln.d_entries, n_ent);
         if ((e = hipGetLastError()) != hipSuccess) return fail(e);
         nl++;
@@ -552,9 +566,11 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, const FigLane
     endlist.clear();
     for (int g : ids) if (ctl[(size_t)g * 4] == 2) endlist.push_back(g);
     if (!endlist.empty()) {
-        if ((e = hipMemcpyAsync(ln.d_items, endlist.data(), endlist.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
-        hipMemsetAsync(db.queue_head, 0, 4, stream);
-        if ((e = launch_any(ctx, c, db, stream, 3, std::min(capacity, (int)endlist.size()), ln.d_items, (int)endlist.size())) != hipSuccess) return fail(e);
+        if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);      // h_items is reused: the last round's upload must have left it
+        memcpy(ln.h_items, endlist.data(), endlist.size() * 4);
+        if ((e = hipMemcpyAsync(ln.d_items, ln.h_items, endlist.size() * 4, hipMemcpyHostToDevice, stream)) != hipSuccess) return fail(e);
+        if ((e = launch_any(ctx, c, db, stream, 3, std::min(capacity, (int)endlist.size()), ln.d_items, (int)endlist.size(), ln.qsel)) != hipSuccess) return fail(e);
+        ln.qsel ^= 1;
         nl++;
     }
     (void)n_cls;
