@@ -40,3 +40,17 @@ def test_emulated_engine_fuzz(seed, tmp_path):
     from tools.fuzz_ref import mk
     from tools.compare_emu import run_one
     assert run_one(mk(seed), str(tmp_path), exe=util.EMU, verbose=False)
+
+
+@pytest.mark.parametrize("chunk", ["1", "3", "64"])
+def test_emulated_scheduler_chunking_is_invariant(chunk, tmp_path, monkeypatch):
+    """The candidate-parallel orchestration (speculate CHUNK candidates, replay the bookkeeping in order) must give
+    the reference's bytes whatever the chunk size; FIG_SCHED=seq (one pass per gap) is covered by the other tests'
+    default path only on the GPU, so it is pinned here too."""
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    monkeypatch.setenv("FIG_EMU_CHUNK", chunk)
+    for seed in (411, 412):
+        assert run_one(mk(seed), str(tmp_path / f"c{seed}"), exe=util.EMU, verbose=False)
+    monkeypatch.setenv("FIG_SCHED", "seq")
+    assert run_one(mk(413), str(tmp_path / "seq"), exe=util.EMU, verbose=False)
