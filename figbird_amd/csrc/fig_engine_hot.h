@@ -138,14 +138,18 @@ FIG_D double fig_hot_chain_e(const FigPQ *PQ, const double *Q4, int ncolE, fig_c
 // ops, so the memory latencies overlap each other and (with a second wave on the SIMD) the arithmetic.
 struct FigEBlk { double kk[16]; FigPQ va[8], vb[8]; };
 
-template <bool LDS>
+// DX > 0: the second placement sits DX columns right of the first (xb == xa + DX), so both reads of a step share one
+// address register and the second uses the instruction's constant offset.  DX == 0: independent xb.
+// The last block of a chain may be partial: its loads run past the read's end (2-bit codes there are 0 and the
+// table / weight-pair arrays continue, so the addresses are valid) and only the first `n` steps are multiplied in.
+template <bool LDS, int DX>
 FIG_D void fig_eblk_load(FigEBlk &B, const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, int bi, int xa, int xb) {
     const int j0 = bi * 8;
     const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
     fig_cdp k2 = kt + 2 * j0;
 #pragma unroll
     for (int q = 0; q < 16; q++) B.kk[q] = k2[q];
-    const FigPQ *ca = PQ + xa + j0, *cb = PQ + xb + j0;
+    const FigPQ *ca = PQ + xa + j0, *cb = DX > 0 ? ca + DX : PQ + xb + j0;
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; B.va[jj] = ca[r]; B.vb[jj] = cb[r]; }
 }
@@ -156,36 +160,39 @@ FIG_D void fig_eblk_compute(const FigEBlk &B, double &pa, double &pb) {
         pb *= (B.vb[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.vb[jj].q);
     }
 }
+FIG_D void fig_eblk_compute_n(const FigEBlk &B, int n, double &pa, double &pb) {      // n in 1..8, wave-uniform
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        if (jj < n) {
+            pa *= (B.va[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.va[jj].q);
+            pb *= (B.vb[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.vb[jj].q);
+        }
+    }
+}
 
 // Software-pipelined: the loads of block i+1 (scalar table + 16 LDS reads) are issued before the 64 FP64 ops
 // of block i, so their latency is covered by arithmetic of the same wave.
-template <bool LDS>
+template <bool LDS, int DX>
 FIG_D void fig_hot_chain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, int nw2, fig_cdp kt, int len, int xa, int xb, double &pa, double &pb) {
-    const int nblk = len >> 3;
-    if (nblk > 0) {
-        FigEBlk A, Bk;
-        fig_eblk_load<LDS>(A, PQ, ncolE, pk, kt, 0, xa, xb);
-        int bi = 0;
-        for (; bi + 2 <= nblk - 1; bi += 2) {
-            fig_eblk_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
-            fig_eblk_compute(A, pa, pb);
-            fig_eblk_load<LDS>(A, PQ, ncolE, pk, kt, bi + 2, xa, xb);
-            fig_eblk_compute(Bk, pa, pb);
-        }
-        // here block `bi` is loaded in A; blocks bi+1 .. nblk-1 remain (0 or 1 of them)
-        if (bi + 1 <= nblk - 1) {
-            fig_eblk_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
-            fig_eblk_compute(A, pa, pb);
-            fig_eblk_compute(Bk, pa, pb);
-        } else fig_eblk_compute(A, pa, pb);
+    (void)nw2;
+    const int nblk = (len + 7) >> 3;                 // the last one holds len - 8*(nblk-1) steps
+    const int nlast = len - 8 * (nblk - 1);
+    if (nblk <= 0) return;
+    FigEBlk A, Bk;
+    fig_eblk_load<LDS, DX>(A, PQ, ncolE, pk, kt, 0, xa, xb);
+    int bi = 0;
+    for (; bi + 2 <= nblk - 1; bi += 2) {
+        fig_eblk_load<LDS, DX>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+        fig_eblk_compute(A, pa, pb);
+        fig_eblk_load<LDS, DX>(A, PQ, ncolE, pk, kt, bi + 2, xa, xb);
+        fig_eblk_compute(Bk, pa, pb);
     }
-    for (int j = nblk * 8; j < len; j++) {
-        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
-        const double ome = kt[2 * j], e = kt[2 * j + 1];
-        const FigPQ va = PQ[b * ncolE + xa + j], vb = PQ[b * ncolE + xb + j];
-        pa *= (va.p * ome + e * va.q);
-        pb *= (vb.p * ome + e * vb.q);
-    }
+    // here block `bi` is loaded in A; blocks bi+1 .. nblk-1 remain (0 or 1 of them)
+    if (bi + 1 <= nblk - 1) {
+        fig_eblk_load<LDS, DX>(Bk, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+        fig_eblk_compute(A, pa, pb);
+        fig_eblk_compute_n(Bk, nlast, pa, pb);
+    } else fig_eblk_compute_n(A, nlast, pa, pb);
 }
 
 template <bool LDS>
@@ -224,14 +231,14 @@ FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, f
 // ACHIEVED), none of them can be the arg-max and the rest of the round is skipped.  Returns false if pruned.
 struct FigMBlk { double kk[16]; double va[8], vb[8]; };
 
-template <bool LDS>
+template <bool LDS, int DX>
 FIG_D void fig_mblk_load(FigMBlk &B, const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int bi, int xa, int xb) {
     const int j0 = bi * 8;
     const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
     fig_cdp k2 = mt + 2 * j0;
 #pragma unroll
     for (int q = 0; q < 16; q++) B.kk[q] = k2[q];
-    const double *ca = C + xa + j0, *cb = C + xb + j0;
+    const double *ca = C + xa + j0, *cb = DX > 0 ? ca + DX : C + xb + j0;
 #pragma unroll
     for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; B.va[jj] = ca[r]; B.vb[jj] = cb[r]; }
 }
@@ -243,42 +250,44 @@ FIG_D void fig_mblk_compute(const FigMBlk &B, double &qa, double &qb) {
         qb *= (B.vb[jj] < 0 ? B.kk[2 * jj] : fb);
     }
 }
+FIG_D void fig_mblk_compute_n(const FigMBlk &B, int n, double &qa, double &qb) {     // n in 1..8, wave-uniform
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) {
+        if (jj < n) {
+            const double fa = B.kk[2 * jj + 1] * B.va[jj], fb = B.kk[2 * jj + 1] * B.vb[jj];
+            qa *= (B.va[jj] < 0 ? B.kk[2 * jj] : fa);
+            qb *= (B.vb[jj] < 0 ? B.kk[2 * jj] : fb);
+        }
+    }
+}
 
-// Pruned MLE pair chain, software-pipelined like fig_hot_chain_e2.  Returns false as soon as no live lane of the
-// wave can still reach `bound` (all factors are <= 1, so partial products only shrink); the prefetched block is
-// then simply dropped.
-template <bool LDS>
+// Pruned MLE pair chain, software-pipelined like fig_hot_chain_e2 (incl. the partial last block and DX).  Returns
+// false as soon as no live lane of the wave can still reach `bound` (all factors are <= 1, so partial products only
+// shrink); the prefetched block is then simply dropped.  With DX > 0 a lane whose second placement is outside the
+// window (vb_ok false) still reads xa + DX: inside the table area, result ignored.
+template <bool LDS, int DX>
 FIG_D bool fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
                              double bound, double &qa, double &qb) {
-    const int nblk = len >> 3;
-    if (nblk > 0) {
-        FigMBlk A, Bk;
-        fig_mblk_load<LDS>(A, C, ncolE, pk, mt, 0, xa, xb);
-        int bi = 0;
-        for (; bi + 2 <= nblk - 1; bi += 2) {
-            fig_mblk_load<LDS>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
-            fig_mblk_compute(A, qa, qb);
-            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
-            fig_mblk_load<LDS>(A, C, ncolE, pk, mt, bi + 2, xa, xb);
-            fig_mblk_compute(Bk, qa, qb);
-            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
-        }
-        if (bi + 1 <= nblk - 1) {
-            fig_mblk_load<LDS>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
-            fig_mblk_compute(A, qa, qb);
-            if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
-            fig_mblk_compute(Bk, qa, qb);
-        } else fig_mblk_compute(A, qa, qb);
+    const int nblk = (len + 7) >> 3;
+    const int nlast = len - 8 * (nblk - 1);
+    if (nblk <= 0) return true;
+    FigMBlk A, Bk;
+    fig_mblk_load<LDS, DX>(A, C, ncolE, pk, mt, 0, xa, xb);
+    int bi = 0;
+    for (; bi + 2 <= nblk - 1; bi += 2) {
+        fig_mblk_load<LDS, DX>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
+        fig_mblk_compute(A, qa, qb);
+        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+        fig_mblk_load<LDS, DX>(A, C, ncolE, pk, mt, bi + 2, xa, xb);
+        fig_mblk_compute(Bk, qa, qb);
         if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
     }
-    for (int j = nblk * 8; j < len; j++) {
-        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
-        const double m3 = mt[2 * j], e = mt[2 * j + 1];
-        const double va = C[b * ncolE + xa + j], vb = C[b * ncolE + xb + j];
-        const double fa = e * va, fb = e * vb;
-        qa *= (va < 0 ? m3 : fa);
-        qb *= (vb < 0 ? m3 : fb);
-    }
+    if (bi + 1 <= nblk - 1) {
+        fig_mblk_load<LDS, DX>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
+        fig_mblk_compute(A, qa, qb);
+        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+        fig_mblk_compute_n(Bk, nlast, qa, qb);
+    } else fig_mblk_compute_n(A, nlast, qa, qb);
     return true;
 }
 
@@ -446,7 +455,13 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                     int ob = o + stride;
                     double pa = U.insd[w.tis0 + w.dir * o], pb = U.insd[w.tis0 + w.dir * ob];
                     FIG_T0(E);
-                    fig_hot_chain_e2<LDS>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+#ifdef FIG_EMU
+                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+#else
+                    if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+#endif
                     FIG_TICK(E, 9);
                     double ta = fig_log10(pa), tb = fig_log10(pb);
                     if (ta > best.v) { best.v = ta; best.o = o; }
@@ -660,7 +675,11 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     double qa = 1, qb = 1;
                     // out-of-window lanes read inside the table (clamped) and are ignored
                     const int xa = (va_ok ? oa : w.hi) + xoff, xb = (vb_ok ? ob : w.hi) + xoff;
-                    bool full = fig_hot_chain_m2p<LDS>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, qa, qb);
+#ifdef FIG_EMU
+                    bool full = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, qa, qb);
+#else
+                    bool full = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, (va_ok ? oa : ob - 64) + xoff, 0, va_ok, vb_ok, bound, qa, qb);
+#endif
                     if (full) {
                         if (va_ok && (qa > best.v || (qa == best.v && best.o != FIG_NOPOS && oa < best.o))) { best.v = qa; best.o = oa; }
                         if (vb_ok && (qb > best.v || (qb == best.v && best.o != FIG_NOPOS && ob < best.o))) { best.v = qb; best.o = ob; }
