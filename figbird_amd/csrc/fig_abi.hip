@@ -23,6 +23,14 @@
 // ------------------------------------------------------------------------------------- kernel
 // LDS carve-up (doubles first so everything stays 8-byte aligned), LDS_TAB only:
 //   PQ[4][ncolE] (16 B each)  Q4[ncolE]  wbuf[nteams][Wcap]  | FigState  gs[capGl]  rb[FIG_MAX_READLEN+8]
+#ifdef FIG_PROF
+#define FIG_PROF_BEGIN() const unsigned long long _k0 = __builtin_readcyclecounter()
+#define FIG_PROF_FLUSH() do { if (E.lane == 0) { atomicAdd(&B.counters[30], E.wait_cycles); atomicAdd(&B.counters[31], (unsigned long long)__builtin_readcyclecounter() - _k0); \
+    for (int i = 0; i < 22; i++) if (E.prof[i]) atomicAdd(&B.counters[8 + i], E.prof[i]); } } while (0)
+#else
+#define FIG_PROF_BEGIN() ((void)0)
+#define FIG_PROF_FLUSH() ((void)0)
+#endif
 struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel; };
 
 FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
@@ -30,6 +38,7 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
     E.capG = A.capG; E.flops = 0; E.wait_cycles = 0;
+    for (int i = 0; i < 22; i++) E.prof[i] = 0;
     E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
     fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &work);
@@ -65,9 +74,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
     if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
-#ifdef FIG_PROF
-    const unsigned long long _k0 = __builtin_readcyclecounter();
-#endif
+    FIG_PROF_BEGIN();
     while (true) {
         if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
@@ -79,9 +86,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
         fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
         fig_fill_gap<LDS_TAB>(E);
     }
-#ifdef FIG_PROF
-    if (E.lane == 0) { atomicAdd(&B.counters[30], E.wait_cycles); atomicAdd(&B.counters[31], (unsigned long long)__builtin_readcyclecounter() - _k0); }
-#endif
+    FIG_PROF_FLUSH();
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
 }
 
@@ -121,6 +126,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_eval_kernel(FigDe
     FigEng E; FigScr work;
     fig_eng_init(E, M, B, A, LDS_TAB, work);
     if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
+    FIG_PROF_BEGIN();
     while (true) {
         if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
         __syncthreads();
@@ -133,6 +139,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_eval_kernel(FigDe
         fig_spec_eval<LDS_TAB>(E, work, P, it.y, it.z, E.g->capGg);
         __syncthreads();
     }
+    FIG_PROF_FLUSH();
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
 }
 
@@ -672,8 +679,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1);
     ctx->stats.d2h_ms = ms;
 #ifdef FIG_PROF
-    { const char *nm[14] = {"A.wait.w0", "B.wait.w0", "M.wait.w0", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain.w0", "A.logexp.w0", "A.work.w0", "B.work.w0", "M.work.w0"};
-      for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %.3f Gcycles (sum over workgroups)\n", nm[i], cnt[8 + i] / 1e9);
+    { const char *nm[14] = {"A.wait", "B.wait", "-", "M.finish", "PR.pre", "PR.estep", "PR.mid", "PR.mle", "PR.post", "A.chain", "A.logexp", "A.work", "B.work", "M.chains"};
+      for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %8.1f Gcycles = %5.1f %% of wave-cycles\n", nm[i], cnt[8 + i] / 1e9, cnt[31] ? 100.0 * cnt[8 + i] / cnt[31] : 0.0);
       fprintf(stderr, "[figprof] barrier wait %.3f of %.3f wave-Gcycles = %.1f %%\n", cnt[30] / 1e9, cnt[31] / 1e9, cnt[31] ? 100.0 * cnt[30] / cnt[31] : 0.0); }
 #endif
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);

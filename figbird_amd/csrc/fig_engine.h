@@ -65,11 +65,12 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { ato
 #define FIG_PLB_TEAMS 8
 #define FIG_PLB_BYTES (FIG_PLB_TEAMS * 64 * 4)
 
-// Optional phase timers (diagnostic build only: -DFIG_PROF).  Lane 0 of each workgroup adds s_memtime
-// deltas to B.counters[8+slot]; never enabled in the shipped library.
-#if defined(FIG_PROF) && (FIG_PROF >= 2) && !defined(FIG_EMU)
-#define FIG_T0(E) unsigned long long _fig_t = ((E).tid == 0) ? __builtin_readcyclecounter() : 0ULL
-#define FIG_TICK(E, slot) do { if ((E).tid == 0) { unsigned long long _n = __builtin_readcyclecounter(); atomicAdd(&(E).B->counters[8 + (slot)], _n - _fig_t); _fig_t = _n; } } while (0)
+// Optional phase timers (diagnostic build only: -DFIG_PROF).  Every lane accumulates s_memtime deltas in its own
+// FigEng::prof[] (no atomics inside the loops); lane 0 of each wave adds them to B.counters[8+slot] when the kernel
+// ends, so the printed figures are sums over WAVES.  Never enabled in the shipped library.
+#if defined(FIG_PROF) && !defined(FIG_EMU)
+#define FIG_T0(E) unsigned long long _fig_t = __builtin_readcyclecounter()
+#define FIG_TICK(E, slot) do { unsigned long long _n = __builtin_readcyclecounter(); (E).prof[slot] += _n - _fig_t; _fig_t = _n; } while (0)
 #else
 #define FIG_T0(E) do { } while (0)
 #define FIG_TICK(E, slot) do { } while (0)
@@ -250,6 +251,7 @@ struct FigEng {
     int capG;
     unsigned long long flops;        // per-lane algorithmic flop count
     unsigned long long wait_cycles;  // FIG_PROF only: cycles spent in workgroup barriers
+    unsigned long long prof[22];     // FIG_PROF only: phase timers
 };
 
 // ---------------------------------------------------------------------------------------
