@@ -195,6 +195,44 @@ FIG_D void fig_hot_chain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, int nw2, f
     } else fig_eblk_compute_n(A, nlast, pa, pb);
 }
 
+// One placement per lane, same pipeline (the short last round of a read).
+struct FigEBlk1 { double kk[16]; FigPQ va[8]; };
+template <bool LDS>
+FIG_D void fig_eblk1_load(FigEBlk1 &B, const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, int bi, int xa) {
+    const int j0 = bi * 8;
+    const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
+    fig_cdp k2 = kt + 2 * j0;
+#pragma unroll
+    for (int q = 0; q < 16; q++) B.kk[q] = k2[q];
+    const FigPQ *ca = PQ + xa + j0;
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) B.va[jj] = ca[(int)((w >> (2 * jj)) & 3) * ncolE + jj];
+}
+FIG_D void fig_eblk1_compute_n(const FigEBlk1 &B, int n, double &pa) {
+#pragma unroll
+    for (int jj = 0; jj < 8; jj++) if (jj < n) pa *= (B.va[jj].p * B.kk[2 * jj] + B.kk[2 * jj + 1] * B.va[jj].q);
+}
+template <bool LDS>
+FIG_D void fig_hot_chain_e1(const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, int len, int xa, double &pa) {
+    const int nblk = (len + 7) >> 3;
+    const int nlast = len - 8 * (nblk - 1);
+    if (nblk <= 0) return;
+    FigEBlk1 A, Bk;
+    fig_eblk1_load<LDS>(A, PQ, ncolE, pk, kt, 0, xa);
+    int bi = 0;
+    for (; bi + 2 <= nblk - 1; bi += 2) {
+        fig_eblk1_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa);
+        fig_eblk1_compute_n(A, 8, pa);
+        fig_eblk1_load<LDS>(A, PQ, ncolE, pk, kt, bi + 2, xa);
+        fig_eblk1_compute_n(Bk, 8, pa);
+    }
+    if (bi + 1 <= nblk - 1) {
+        fig_eblk1_load<LDS>(Bk, PQ, ncolE, pk, kt, bi + 1, xa);
+        fig_eblk1_compute_n(A, 8, pa);
+        fig_eblk1_compute_n(Bk, nlast, pa);
+    } else fig_eblk1_compute_n(A, nlast, pa);
+}
+
 template <bool LDS>
 FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, fig_cdp mt, int len, int xa, int xb, double &qa, double &qb) {
     const int nblk = len >> 3;
@@ -451,26 +489,41 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             const int stride = T * U.wsz;
             int o = w.lo + wit * U.wsz + lane;
             if (!hasN && !clipped) {
-                for (; o + stride <= w.hi; o += 2 * stride) {
-                    int ob = o + stride;
-                    double pa = U.insd[w.tis0 + w.dir * o], pb = U.insd[w.tis0 + w.dir * ob];
+                // wave-uniform rounds: a pair round while this wave still has a second half (its lanes past the window
+                // are masked: they read inside the LDS image and are ignored), then at most one single round
+                int ob0 = w.lo + wit * U.wsz;                                   // lane 0 of the round
+                for (; ob0 + stride <= w.hi; ob0 += 2 * stride) {
+                    const int oa = ob0 + lane, ob = oa + stride;
+                    const bool vb = ob <= w.hi;
+                    double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * (vb ? ob : oa)];
                     FIG_T0(E);
 #ifdef FIG_EMU
-                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
 #else
-                    if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
-                    else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
-                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, o + xoff, ob + xoff, pa, pb);
+                    if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+                    else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
 #endif
                     FIG_TICK(E, 9);
-                    double ta = fig_log10(pa), tb = fig_log10(pb);
-                    if (ta > best.v) { best.v = ta; best.o = o; }
-                    if (tb > best.v) { best.v = tb; best.o = ob; }
-                    wrow[o] = fig_exp(0.5 * ta);
-                    wrow[ob] = fig_exp(0.5 * tb);
+                    const double ta = fig_log10(pa), tb = fig_log10(pb);
+                    const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
+                    if (ta > best.v) { best.v = ta; best.o = oa; }
+                    wrow[oa] = wa;
+                    if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
                     FIG_TICK(E, 10);
-                    nplace += 2;
+                    nplace += vb ? 2 : 1;
                 }
+                if (ob0 <= w.hi) {
+                    const int oa = ob0 + lane;
+                    const bool va = oa <= w.hi;
+                    const int ca = va ? oa : w.hi;
+                    double pa = U.insd[w.tis0 + w.dir * ca];
+                    fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
+                    const double ta = fig_log10(pa);
+                    const double wa = fig_exp(0.5 * ta);
+                    if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; }
+                }
+                o = w.hi + 1;
             }
             for (; o <= w.hi; o += stride) {
                 int tis = w.tis0 + w.dir * o;
