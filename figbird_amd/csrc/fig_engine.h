@@ -71,7 +71,9 @@ FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { ato
 #if defined(FIG_PROF) && !defined(FIG_EMU)
 #define FIG_T0(E) unsigned long long _fig_t = __builtin_readcyclecounter()
 #define FIG_TICK(E, slot) do { unsigned long long _n = __builtin_readcyclecounter(); (E).prof[slot] += _n - _fig_t; _fig_t = _n; } while (0)
+#define FIG_COUNT(E, slot, n) do { (E).prof[slot] += (n); } while (0)
 #else
+#define FIG_COUNT(E, slot, n) do { } while (0)
 #define FIG_T0(E) do { } while (0)
 #define FIG_TICK(E, slot) do { } while (0)
 #endif

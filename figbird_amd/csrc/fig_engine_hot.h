@@ -65,6 +65,18 @@ FIG_D double fig_wave_max(double v) {
     return v;
 #endif
 }
+FIG_D unsigned long long fig_ballot(bool p) {
+#ifdef FIG_EMU
+    return p ? 1ULL : 0ULL;
+#else
+    return __ballot(p);
+#endif
+}
+FIG_D double fig_bcast_d(double v) {       // lane 0's value in every lane
+    long long bits; memcpy(&bits, &v, 8); bits = fig_u64(bits); memcpy(&v, &bits, 8);
+    return v;
+}
+
 FIG_D bool fig_wave_any(bool p) {
 #ifdef FIG_EMU
     return p;
@@ -299,34 +311,45 @@ FIG_D void fig_mblk_compute_n(const FigMBlk &B, int n, double &qa, double &qb) {
     }
 }
 
-// Pruned MLE pair chain, software-pipelined like fig_hot_chain_e2 (incl. the partial last block and DX).  Returns
-// false as soon as no live lane of the wave can still reach `bound` (all factors are <= 1, so partial products only
-// shrink); the prefetched block is then simply dropped.  With DX > 0 a lane whose second placement is outside the
-// window (vb_ok false) still reads xa + DX: inside the table area, result ignored.
+// Pruned MLE pair chain, software-pipelined like fig_hot_chain_e2 (incl. the partial last block and DX).  All factors
+// are <= 1, so partial products only shrink: a lane is dead once its product is below `bound`.  After every block:
+//   no live lane            -> return 0 (nothing in this round can reach the bound);
+//   `few` live lanes, and finishing them one by one (fig_mle_serial, ~4 blocks' time each) is cheaper than running
+//   the remaining blocks    -> return 1 with their lane masks in ma / mb;
+//   otherwise continue; return 2 with the finished products in qa / qb.
+// The prefetched block of an early return is simply dropped.  With DX > 0 a lane whose second placement is outside
+// the window (vb_ok false) still reads xa + DX: inside the table area, result ignored.
+FIG_D int fig_popc64(unsigned long long m) { int c = 0; for (; m; m &= m - 1) c++; return c; }
+#define FIG_M2P_CHECK(done) do { \
+        ma = fig_ballot(va_ok && qa >= bound); mb = fig_ballot(vb_ok && qb >= bound); \
+        if (!(ma | mb)) return 0; \
+        if (allow_few) { const int alive_ = fig_popc64(ma) + fig_popc64(mb); if (alive_ <= 8 && (nblk - (done)) > 4 * alive_) return 1; } \
+    } while (0)
 template <bool LDS, int DX>
-FIG_D bool fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
-                             double bound, double &qa, double &qb) {
+FIG_D int fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
+                            double bound, bool allow_few, double &qa, double &qb, unsigned long long &ma, unsigned long long &mb) {
     const int nblk = (len + 7) >> 3;
     const int nlast = len - 8 * (nblk - 1);
-    if (nblk <= 0) return true;
+    ma = mb = 0;
+    if (nblk <= 0) return 2;
     FigMBlk A, Bk;
     fig_mblk_load<LDS, DX>(A, C, ncolE, pk, mt, 0, xa, xb);
     int bi = 0;
     for (; bi + 2 <= nblk - 1; bi += 2) {
         fig_mblk_load<LDS, DX>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
         fig_mblk_compute(A, qa, qb);
-        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+        FIG_M2P_CHECK(bi + 1);
         fig_mblk_load<LDS, DX>(A, C, ncolE, pk, mt, bi + 2, xa, xb);
         fig_mblk_compute(Bk, qa, qb);
-        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+        FIG_M2P_CHECK(bi + 2);
     }
     if (bi + 1 <= nblk - 1) {
         fig_mblk_load<LDS, DX>(Bk, C, ncolE, pk, mt, bi + 1, xa, xb);
         fig_mblk_compute(A, qa, qb);
-        if (!fig_wave_any((va_ok && qa >= bound) || (vb_ok && qb >= bound))) return false;
+        FIG_M2P_CHECK(bi + 1);
         fig_mblk_compute_n(Bk, nlast, qa, qb);
     } else fig_mblk_compute_n(A, nlast, qa, qb);
-    return true;
+    return 2;
 }
 
 // MLE product chain of one placement.  C[to*ncolE + xe] = -1 when the consensus base equals `to`,
@@ -669,6 +692,64 @@ FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
 #endif
 }
 
+// Full MLE product of ONE placement, by the whole wave: the lanes compute the read's len factors side by side
+// (factor j = m3[j] on a match, e[j]*T[from][to] otherwise -- the same two operations as the chain), park them in
+// fbuf, and then every lane multiplies them up in the reference's order j = 0, 1, ...; so the result is bit-identical
+// to the lane-per-placement chain but costs ~len dependent multiplies instead of a whole 128-placement round.
+// fbuf: >= len doubles private to the wave (LDS ops of one wave execute in order, so no barrier is needed).
+#define FIG_MLE_FB 208
+// What a lane needs of the read for its factors j = lane, lane + wsz, ...: loaded once per read with vector loads
+// (their latency hides behind the first chain blocks), then reused by every serial evaluation of that read.
+struct FigSerLane { int b[4]; double m3[4], e[4]; };
+FIG_D void fig_mle_serial_prep(FigSerLane &L, fig_cu32p pk, fig_cdp mt, int len, int lane, int wsz) {
+#ifndef FIG_EMU
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + k * wsz;
+        const int jj = j < len ? j : 0;
+        L.b[k] = (int)((pk[jj >> 4] >> ((jj & 15) * 2)) & 3);
+        L.m3[k] = mt[2 * jj]; L.e[k] = mt[2 * jj + 1];
+    }
+#else
+    (void)L; (void)pk; (void)mt; (void)len; (void)lane; (void)wsz;
+#endif
+}
+template <bool LDS>
+FIG_D double fig_mle_serial(const FigSerLane &L, const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xe0, double *fbuf, int lane, int wsz) {
+#ifndef FIG_EMU
+    (void)pk; (void)mt;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int j = lane + k * wsz;
+        if (j < len) {
+            const double c = C[L.b[k] * ncolE + xe0 + j];
+            const double f = L.e[k] * c;
+            fbuf[j] = c < 0 ? L.m3[k] : f;
+        }
+    }
+#else
+    (void)L;
+    for (int j = lane; j < len; j += wsz) {
+        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
+        const double m3 = mt[2 * j], e = mt[2 * j + 1];
+        const double c = C[b * ncolE + xe0 + j];
+        const double f = e * c;
+        fbuf[j] = c < 0 ? m3 : f;
+    }
+#endif
+    double q = 1;
+    int j = 0;
+    for (; j + 16 <= len; j += 16) {
+        double f[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) f[k] = fbuf[j + k];
+#pragma unroll
+        for (int k = 0; k < 16; k++) q *= f[k];
+    }
+    for (; j < len; j++) q *= fbuf[j];
+    return q;
+}
+
 // ---------------------------------------------------------------------------------------
 // MLE pass over all unmapped reads.  mode 0: placeReads (Figbird.cpp:3732-3914); mode 1: finalize
 // (:5018-5192).  `gl` = length of the gap string the products are taken against (== S.G except inside
@@ -693,6 +774,10 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
+    // per-wave factor buffer of fig_mle_serial: the weight rows are idle during the MLE pass
+    int nrows = U.nteams; if (nrows > U.nw) nrows = U.nw;
+    const bool use_serial = (long long)nrows * U.Wcap >= (long long)U.nw * FIG_MLE_FB;
+    double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
     for (int c0 = 0; c0 < nU; c0 += nteams) {
         int r = c0 + team;
@@ -718,29 +803,65 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 const int obase = w.lo + wit * U.wsz;               // lane 0 of round 0
                 const int span = w.hi - obase;                      // < 0: nothing for this wave
                 const int nrounds = span < 0 ? 0 : span / (2 * stride) + 1;
-                int r0 = 0;
-                { int h = fig_u(E.scr.hint[r]); if (h != FIG_NOPOS && h >= obase && h <= w.hi) r0 = (h - obase) / (2 * stride); if (r0 >= nrounds) r0 = 0; }
+                // Survivor scheme.  Every factor is <= 1, so a placement's product over a prefix of the read bounds its full
+                // product from above.  With a running maximum `bound` in hand (first from the hinted placement, evaluated on
+                // its own by fig_mle_serial) a round runs the pruned pair chain only until few lanes are still above the
+                // bound; those are then finished one by one, again serially.  Nothing else can be the maximum (or tie it),
+                // so value and arg-max are exactly those of the full scan.
                 double bound = init;
+                FigBest ub; ub.v = init; ub.o = FIG_NOPOS;         // wave-uniform best of the serial evaluations
+                FigSerLane SL;
+                if (use_serial) fig_mle_serial_prep(SL, pk, mt, rs.len, lane, U.wsz);
+                FIG_TICK(E, 14);
+                const int h = fig_u(E.scr.hint[r]);
+                int r0 = 0;
+                if (h != FIG_NOPOS && h >= obase && h <= w.hi) {
+                    r0 = (h - obase) / (2 * stride); if (r0 >= nrounds) r0 = 0;
+                    if (use_serial) {
+                        const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, h + xoff, fbuf, lane, U.wsz);
+                        if (v > init) { ub.v = v; ub.o = h; bound = v; }
+                    }
+                }
+                FIG_TICK(E, 15);
                 for (int q = 0; q < nrounds; q++) {
                     int rr = r0 + q; if (rr >= nrounds) rr -= nrounds;
                     const int oa = obase + lane + 2 * rr * stride, ob = oa + stride;
                     const bool va_ok = oa <= w.hi, vb_ok = ob <= w.hi;
-                    double qa = 1, qb = 1;
+                    nplace += (va_ok ? 1 : 0) + (vb_ok ? 1 : 0);
                     // out-of-window lanes read inside the table (clamped) and are ignored
                     const int xa = (va_ok ? oa : w.hi) + xoff, xb = (vb_ok ? ob : w.hi) + xoff;
+                    double qa = 1, qb = 1;
+                    unsigned long long ma = 0, mb = 0;
 #ifdef FIG_EMU
-                    bool full = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, qa, qb);
+                    const int rc = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, use_serial, qa, qb, ma, mb);
 #else
-                    bool full = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, (va_ok ? oa : ob - 64) + xoff, 0, va_ok, vb_ok, bound, qa, qb);
+                    const int rc = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, oa + xoff, 0, va_ok, vb_ok, bound, use_serial, qa, qb, ma, mb);
 #endif
-                    if (full) {
+                    FIG_TICK(E, 16);
+                    if (rc == 2) {
                         if (va_ok && (qa > best.v || (qa == best.v && best.o != FIG_NOPOS && oa < best.o))) { best.v = qa; best.o = oa; }
                         if (vb_ok && (qb > best.v || (qb == best.v && best.o != FIG_NOPOS && ob < best.o))) { best.v = qb; best.o = ob; }
                         double m = fig_wave_max(best.o == FIG_NOPOS ? init : best.v);
                         if (m > bound) bound = m;
+                    } else if (rc == 1) {
+                        const int base_a = obase + 2 * rr * stride;
+                        for (int half = 0; half < 2; half++) {
+                            unsigned long long m = half ? mb : ma;
+                            while (m) {
+                                int bit = 0; { unsigned long long t = m; while (!(t & 1)) { t >>= 1; bit++; } }
+                                m &= m - 1;
+                                const int os = base_a + bit + (half ? stride : 0);
+                                if (os == ub.o) continue;                       // already evaluated (the hint)
+                                const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                                if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
+                                if (v > bound) bound = v;
+                            }
+                        }
                     }
-                    nplace += (va_ok ? 1 : 0) + (vb_ok ? 1 : 0);
+                    FIG_TICK(E, 17);
                 }
+                // fold the serial results into lane 0's candidate for the wave reduction below
+                if (lane == 0) best = fig_best_merge(best, ub);
                 o = w.hi + 1;
             }
             for (; o <= w.hi; o += stride) {
