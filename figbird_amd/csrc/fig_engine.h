@@ -37,6 +37,7 @@ FIG_D double fig_exp(double x) { return exp(x); }
 FIG_D double fig_pow10(double x) { return pow(10, x); }
 FIG_D int fig_atomic_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
 FIG_D void fig_atomic_max_i32(int *p, int v) { if (v > *p) *p = v; }
+FIG_D int fig_atomic_fetch_add_i32(int *p, int v) { int o = *p; *p += v; return o; }
 FIG_D void fig_atomic_min_i32(int *p, int v) { if (v < *p) *p = v; }
 FIG_D void fig_atomic_or_i32(int *p, int v) { *p |= v; }
 FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
@@ -56,6 +57,7 @@ FIG_D double fig_exp(double x) { return exp(x); }
 FIG_D double fig_pow10(double x) { return pow(10.0, x); }
 FIG_D int fig_atomic_add_i32(int *p, int v) { return atomicAdd(p, v); }
 FIG_D void fig_atomic_max_i32(int *p, int v) { atomicMax(p, v); }
+FIG_D int fig_atomic_fetch_add_i32(int *p, int v) { return atomicAdd(p, v); }
 FIG_D void fig_atomic_min_i32(int *p, int v) { atomicMin(p, v); }
 FIG_D void fig_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
@@ -139,6 +141,7 @@ struct FigState {
     // read teams of the unmapped hot path: one read per team, T waves per team
     int tm_lo[16], tm_hi[16], tm_len[16], tm_tis0[16], tm_dir[16];
     double wv_v[16]; int wv_o[16];   // per-wave partial arg-max
+    int mle_next, pad_mn;            // next read of the MLE pass (waves take reads dynamically)
     int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics
     FigLoop L;
     // useful-work counters of this gap (speculative candidates that are discarded never reach them)

@@ -512,39 +512,66 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             const int stride = T * U.wsz;
             int o = w.lo + wit * U.wsz + lane;
             if (!hasN && !clipped) {
-                // wave-uniform rounds: a pair round while this wave still has a second half (its lanes past the window
-                // are masked: they read inside the LDS image and are ignored), then at most one single round
-                int ob0 = w.lo + wit * U.wsz;                                   // lane 0 of the round
-                for (; ob0 + stride <= w.hi; ob0 += 2 * stride) {
-                    const int oa = ob0 + lane, ob = oa + stride;
-                    const bool vb = ob <= w.hi;
-                    double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * (vb ? ob : oa)];
+                // Wave-uniform rounds.  Full team rounds (2*stride placements: every wave of the team has both halves of
+                // its pair), then the tail of < 2*stride placements is cut into T equal stretches, one per wave, so the
+                // waves of a team finish together: a stretch of more than one wave width runs as a pair round whose second
+                // half is masked (those lanes read inside the LDS image and are ignored), a shorter one as a single round.
+                const int Wn = w.hi - w.lo + 1;
+                const int nfull = Wn > 0 ? Wn / (2 * stride) : 0;
+                for (int k = 0; k < nfull; k++) {
+                    const int oa = w.lo + k * 2 * stride + wit * U.wsz + lane, ob = oa + stride;
+                    double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * ob];
                     FIG_T0(E);
 #ifdef FIG_EMU
-                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
+                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
 #else
                     if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
                     else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
-                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
+                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
 #endif
                     FIG_TICK(E, 9);
                     const double ta = fig_log10(pa), tb = fig_log10(pb);
-                    const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
                     if (ta > best.v) { best.v = ta; best.o = oa; }
-                    wrow[oa] = wa;
-                    if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
+                    if (tb > best.v) { best.v = tb; best.o = ob; }
+                    wrow[oa] = fig_exp(0.5 * ta);
+                    wrow[ob] = fig_exp(0.5 * tb);
                     FIG_TICK(E, 10);
-                    nplace += vb ? 2 : 1;
+                    nplace += 2;
                 }
-                if (ob0 <= w.hi) {
-                    const int oa = ob0 + lane;
-                    const bool va = oa <= w.hi;
-                    const int ca = va ? oa : w.hi;
-                    double pa = U.insd[w.tis0 + w.dir * ca];
-                    fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
-                    const double ta = fig_log10(pa);
-                    const double wa = fig_exp(0.5 * ta);
-                    if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; }
+                {
+                    const int tbase = w.lo + nfull * 2 * stride;
+                    const int nt = w.hi - tbase + 1;                            // 0 .. 2*stride-1
+                    const int per_w = (nt + T - 1) / T;
+                    const int start = tbase + wit * per_w;
+                    int m = w.hi - start + 1; if (m > per_w) m = per_w;        // this wave's stretch: [start, start + m)
+                    if (m > U.wsz) {
+                        const int oa = start + lane, ob = oa + U.wsz;
+                        const bool vb = ob < start + m;
+                        double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * (vb ? ob : oa)];
+                        FIG_T0(E);
+#ifdef FIG_EMU
+                        fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
+#else
+                        fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+#endif
+                        FIG_TICK(E, 9);
+                        const double ta = fig_log10(pa), tb = fig_log10(pb);
+                        const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
+                        if (ta > best.v) { best.v = ta; best.o = oa; }
+                        wrow[oa] = wa;
+                        if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
+                        FIG_TICK(E, 10);
+                        nplace += vb ? 2 : 1;
+                    } else if (m > 0) {
+                        const int oa = start + lane;
+                        const bool va = lane < m;
+                        const int ca = va ? oa : start;
+                        double pa = U.insd[w.tis0 + w.dir * ca];
+                        fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
+                        const double ta = fig_log10(pa);
+                        const double wa = fig_exp(0.5 * ta);
+                        if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; }
+                    }
                 }
                 o = w.hi + 1;
             }
@@ -771,6 +798,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int team = wave, wit = 0;
     const int ncl = mode == 0 ? S.ncols : (gl > cg ? cg : gl);
     for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = 0;
+    if (E.tid == 0) S.mle_next = 0;
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
@@ -779,9 +807,14 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const bool use_serial = (long long)nrows * U.Wcap >= (long long)U.nw * FIG_MLE_FB;
     double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
-    for (int c0 = 0; c0 < nU; c0 += nteams) {
-        int r = c0 + team;
-        bool active = team < nteams && r < nU;
+    (void)nteams; (void)team;
+    while (true) {
+        // waves take reads dynamically (reads differ a lot in cost once pruning works), so the pass ends evenly
+        int r = 0;
+        if (lane == 0) r = fig_atomic_fetch_add_i32(&S.mle_next, 1);
+        r = fig_u(r);
+        if (r >= nU) break;
+        const bool active = true;
         FigReadS rs; rs.len = 0; rs.rev = 0; rs.pos = 0; rs.woff = 0;
         FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
         if (active) {

@@ -114,10 +114,11 @@ def test_bench_shape_matches_oracle_on_a_sample(tmp_path):
     files and checked against the oracle byte for byte."""
     spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=30.0)
     eng, mc = _bench_engine(spec)
-    batch, _ = synth.make_bench_batch(321, 64, spec, gap_lengths=np.array(([12, 40, 90, 500] * 16)))
+    # index 60: a 170-bp gap (candidates up to 510 columns: the 512-thread class, two waves per read)
+    batch, _ = synth.make_bench_batch(321, 64, spec, gap_lengths=np.array(([12, 40, 90, 500] * 15 + [170, 40, 90, 500])))
     res = eng.fill(batch)
     eng.close()
-    sample = [0, 1, 2, 3, 9, 18]
+    sample = [0, 1, 2, 3, 9, 18, 60]
     paths = synth.write_batch_subset(batch, sample, mc, str(tmp_path / "cpu"), spec)
     case_args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
                  "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
