@@ -297,6 +297,9 @@ FIG_D int fig_load_read(const FigEng &E, const FigDevReads &R, long long idx, un
 // workgroup reductions
 struct FigBest { double v; int o; };
 
+// countsGap additions of one placement: read bases that land inside the gap columns [0, G) (Figbird.cpp:3603-3611)
+FIG_D int fig_ovl(int o, int len, int G) { int a = o > 0 ? o : 0, b = o + len < G ? o + len : G; return b > a ? b - a : 0; }
+
 // "first maximum wins": larger v, ties -> smaller o.  Entries with o == FIG_NOPOS are empty.
 FIG_D FigBest fig_best_merge(FigBest a, FigBest b) {
     if (b.o == FIG_NOPOS) return a;

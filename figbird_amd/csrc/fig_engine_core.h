@@ -620,7 +620,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 t = fig_log(t);
                 if (t > best.v) { best.v = t; best.o = o; }
                 E.wbuf[o - w.lo] = fig_pow10(t);
-                E.flops += 4ULL * (unsigned long long)(j1 - j0);
+                E.flops += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(o, len, G);
             }
             best = fig_block_best(E, best);
             FIG_SYNC();

@@ -505,7 +505,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             // insert-size window hold 0.0 so that the column pass needs no window test (x + 0.0 == x exactly)
             double *wrow = W + (long long)team * Wcap + (U.L - 1);
             for (int i = -(U.L - 1) + wit * U.wsz + lane; i < G; i += T * U.wsz) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
-            unsigned long long nplace = 0;
+            unsigned long long nplace = 0, nadd = 0;
             // does the read contain an N?  (then the generic chain handles it)
             bool hasN = false;
             { int nwm = (rs.len + 31) >> 5; uint32_t any = 0; for (int q = 0; q < nwm; q++) any |= pk[nw2 + q]; hasN = any != 0; }
@@ -536,7 +536,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                     wrow[oa] = fig_exp(0.5 * ta);
                     wrow[ob] = fig_exp(0.5 * tb);
                     FIG_TICK(E, 10);
-                    nplace += 2;
+                    nplace += 2; nadd += fig_ovl(oa, rs.len, G) + fig_ovl(ob, rs.len, G);
                 }
                 {
                     const int tbase = w.lo + nfull * 2 * stride;
@@ -561,7 +561,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                         wrow[oa] = wa;
                         if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
                         FIG_TICK(E, 10);
-                        nplace += vb ? 2 : 1;
+                        nplace += vb ? 2 : 1; nadd += fig_ovl(oa, rs.len, G) + (vb ? fig_ovl(ob, rs.len, G) : 0);
                     } else if (m > 0) {
                         const int oa = start + lane;
                         const bool va = lane < m;
@@ -570,7 +570,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                         fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
                         const double ta = fig_log10(pa);
                         const double wa = fig_exp(0.5 * ta);
-                        if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; }
+                        if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; nadd += fig_ovl(oa, rs.len, G); }
                     }
                 }
                 o = w.hi + 1;
@@ -582,9 +582,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 double t = fig_log10(p);
                 if (t > best.v) { best.v = t; best.o = o; }
                 wrow[o] = fig_exp(0.5 * t);
-                nplace++;
+                nplace++; nadd += fig_ovl(o, rs.len, G);
             }
-            E.flops += 4ULL * nplace * (unsigned long long)rs.len;
+            E.flops += 4ULL * nplace * (unsigned long long)rs.len + nadd;
             best = fig_wave_best(E, best);
             if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
             if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;

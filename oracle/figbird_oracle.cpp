@@ -44,7 +44,7 @@ const int windowSize = 12;          // Figbird.cpp:89
 FILE *g_trace = nullptr;
 int g_trace_level = 0;
 long g_place_calls = 0;
-double g_flops = 0;                 // algorithmic FP64 flops (SURVEY.md §8d formula)
+double g_flops = 0;                 // algorithmic FP64 flops: 4 per E-step base, 1 per MLE base, 1 per countsGap add
 
 // ---------------------------------------------------------------- scaffold -------------
 struct Scaffolds {

@@ -54,3 +54,12 @@ def test_emulated_scheduler_chunking_is_invariant(chunk, tmp_path, monkeypatch):
         assert run_one(mk(seed), str(tmp_path / f"c{seed}"), exe=util.EMU, verbose=False)
     monkeypatch.setenv("FIG_SCHED", "seq")
     assert run_one(mk(413), str(tmp_path / "seq"), exe=util.EMU, verbose=False)
+
+
+@pytest.mark.parametrize("seed", [421, 422, 423])
+def test_work_counters_match_oracle(seed, tmp_path):
+    """placeReads calls and algorithmic flops (4 per E-step base, 1 per MLE base, 1 per countsGap add: SURVEY §8d) are
+    counted by the oracle and by the engine; bench.py's roofline uses the engine's, so they must be the same number."""
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    assert run_one(mk(seed), str(tmp_path), exe=util.EMU, verbose=False, trace=True)

@@ -173,3 +173,12 @@ def test_scheduler_modes_agree(monkeypatch):
         for x, y in zip(a, b):
             assert tuple(x[:3]) == tuple(y[:3]), f"gap {g}"
             assert x[3] == y[3] or (np.isnan(x[3]) and np.isnan(y[3])), f"gap {g}: {x} vs {y}"
+
+
+@pytest.mark.parametrize("seed", [531, 532])
+def test_gpu_work_counters_match_oracle(seed, tmp_path):
+    """The device's useful-work counters (placeReads calls, algorithmic flops; discarded speculation excluded) equal the
+    oracle's: they are what bench.py's roofline figure is computed from."""
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    assert run_one(mk(seed), str(tmp_path), exe=util.FIGFILL, verbose=False, trace=True)

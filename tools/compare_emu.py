@@ -33,6 +33,17 @@ def run_one(case, base, exe=EMU, verbose=True, trace=False):
                 if a and b:
                     for x, y in zip(a.splitlines(), b.splitlines()):
                         if x != y: print("   ora:", x[:200]); print("   emu:", y[:200]); break
+    if trace:
+        # useful-work counters: placeReads calls and algorithmic flops must be identical (same control flow)
+        def stats(fn):
+            for l in open(fn):
+                if l.startswith("STATS"):
+                    return l.split("\t")[1:3]
+            return None
+        sa, sb = stats(env["FIG_ORACLE_TRACE"]), stats(env["FIGFILL_TRACE"])
+        if sa is None or sb is None or int(sa[0]) != int(sb[0]) or float(sa[1]) != float(sb[1]):
+            ok = False
+            if verbose: print("  DIFF STATS", sa, sb)
     if verbose:
         print(f"{case.name}: {'OK' if ok else 'MISMATCH'} oracle {to:.2f}s emu {te:.2f}s rc {ro.returncode}/{re_.returncode} {re_.stderr[-300:]}")
     return ok
