@@ -684,8 +684,27 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         fig_hot_mle<LDS>(E, gapoffset, 0, G, left, right);
         FIG_TICK(E, 7);
         for (int x = E.tid; x < S.ncols; x += E.nt) for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = (double)E.scr.nci[j * cg + x];
-        if (E.tid == 0) {                                  // ordered likelihood sum (:3852-3862)
-            for (int r = 0; r < nU; r++) { if (E.scr.accf[r]) maxLikelihood += E.scr.maxlv[r]; else maxLikelihood += -50; }
+        // ordered likelihood sum (:3852-3862): the terms are fetched wave-wide (one coalesced load per 64 reads) and then
+        // added one at a time, in read order, by every lane of the first wave alike (v_readlane broadcast)
+        if (E.tid < E.wsz) {
+            for (int r0 = 0; r0 < nU; r0 += E.wsz) {
+                const int r = r0 + E.lane;
+                double term = 0;
+                if (r < nU) term = E.scr.accf[r] ? E.scr.maxlv[r] : -50.0;
+                const int n = nU - r0 < E.wsz ? nU - r0 : E.wsz;
+#ifdef FIG_EMU
+                for (int k = 0; k < n; k++) maxLikelihood += term;
+#else
+                long long bits; memcpy(&bits, &term, 8);
+                const int lo32 = (int)(bits & 0xffffffffLL), hi32 = (int)(bits >> 32);
+                for (int k = 0; k < n; k++) {
+                    const unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo32, k), h = (unsigned int)__builtin_amdgcn_readlane(hi32, k);
+                    const long long b2 = (long long)(((unsigned long long)h << 32) | l);
+                    double t; memcpy(&t, &b2, 8);
+                    maxLikelihood += t;
+                }
+#endif
+            }
         }
         FIG_SYNC();
         fig_compute_sequence(E, 1, 1);
