@@ -683,6 +683,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
       for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %8.1f Gcycles = %5.1f %% of wave-cycles\n", nm[i], cnt[8 + i] / 1e9, cnt[31] ? 100.0 * cnt[8 + i] / cnt[31] : 0.0);
       { const char *mn[4] = {"M.setup", "M.hint", "M.rounds", "M.surv"};
         for (int i = 0; i < 4; i++) fprintf(stderr, "[figprof] %-9s %8.1f Gcycles = %5.1f %% of wave-cycles\n", mn[i], cnt[22 + i] / 1e9, cnt[31] ? 100.0 * cnt[22 + i] / cnt[31] : 0.0); }
+      fprintf(stderr, "[figprof] raw slots:"); for (int i = 0; i < 22; i++) fprintf(stderr, " %d:%.1f", i, cnt[8 + i] / 1e9); fprintf(stderr, "\n");
       fprintf(stderr, "[figprof] barrier wait %.3f of %.3f wave-Gcycles = %.1f %%\n", cnt[30] / 1e9, cnt[31] / 1e9, cnt[31] ? 100.0 * cnt[30] / cnt[31] : 0.0); }
 #endif
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);
