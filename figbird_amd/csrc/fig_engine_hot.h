@@ -518,9 +518,14 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 // half is masked (those lanes read inside the LDS image and are ignored), a shorter one as a single round.
                 const int Wn = w.hi - w.lo + 1;
                 const int nfull = Wn > 0 ? Wn / (2 * stride) : 0;
+                // insert-size terms of the next round are fetched before the current round's chains (their latency would
+                // otherwise sit in front of the first multiply)
+                double pa_n = 0, pb_n = 0;
+                if (nfull > 0) { const int oa0 = w.lo + wit * U.wsz + lane; pa_n = U.insd[w.tis0 + w.dir * oa0]; pb_n = U.insd[w.tis0 + w.dir * (oa0 + stride)]; }
                 for (int k = 0; k < nfull; k++) {
                     const int oa = w.lo + k * 2 * stride + wit * U.wsz + lane, ob = oa + stride;
-                    double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * ob];
+                    double pa = pa_n, pb = pb_n;
+                    if (k + 1 < nfull) { pa_n = U.insd[w.tis0 + w.dir * (oa + 2 * stride)]; pb_n = U.insd[w.tis0 + w.dir * (ob + 2 * stride)]; }
                     FIG_T0(E);
 #ifdef FIG_EMU
                     fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
