@@ -802,14 +802,20 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int wave = fig_u(E.wave), lane = E.lane;
     const int team = wave, wit = 0;
     const int ncl = mode == 0 ? S.ncols : (gl > cg ? cg : gl);
-    for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = 0;
+    // integer pile-up of the accepted reads: in the idle weight rows (LDS atomics) when they have room behind the
+    // per-wave factor buffers, else straight in the scratch slab; copied out after the pass
+    int nrows = U.nteams; if (nrows > U.nw) nrows = U.nw;
+    const bool use_serial = (long long)nrows * U.Wcap >= (long long)U.nw * FIG_MLE_FB;
+    const long long fb_doubles = use_serial ? (long long)U.nw * FIG_MLE_FB : 0;
+    const bool nci_lds = LDS && (long long)nrows * U.Wcap - fb_doubles >= (5LL * ncl + 1) / 2 + 1;
+    int *nl = nci_lds ? (int *)(fig_w_ptr<LDS>(E) + fb_doubles) : E.scr.nci;
+    const int nst = nci_lds ? ncl : cg;             // row stride of the pile-up
+    for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) nl[j * nst + x] = 0;
     if (E.tid == 0) S.mle_next = 0;
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
     // per-wave factor buffer of fig_mle_serial: the weight rows are idle during the MLE pass
-    int nrows = U.nteams; if (nrows > U.nw) nrows = U.nw;
-    const bool use_serial = (long long)nrows * U.Wcap >= (long long)U.nw * FIG_MLE_FB;
     double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
     (void)nteams; (void)team;
@@ -924,7 +930,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 int nw2 = (rs.len + 15) >> 4;
                 for (int j = lane; j < rs.len; j += U.wsz) {
                     int x = of + j;
-                    if (x >= 0 && x < gl) fig_atomic_add_i32(&E.scr.nci[fig_sbase(pk, nw2, j) * cg + x], 1);
+                    if (x >= 0 && x < gl && x < ncl) fig_atomic_add_i32(&nl[fig_sbase(pk, nw2, j) * nst + x], 1);
                 }
             }
             if (lane == 0) {
@@ -960,6 +966,10 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
         FIG_TICK(E, 3);
     }
     FIG_SYNC();
+    if (nci_lds) {
+        for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = nl[j * nst + x];
+        FIG_SYNC();
+    }
 }
 
 #endif
