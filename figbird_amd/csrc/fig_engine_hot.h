@@ -403,7 +403,7 @@ FIG_D void fig_build_mle_table(FigEng &E, int G, int left, int right) {
     FIG_SYNC();
 }
 
-struct FigReadS { int len, rev, pos; long long woff; };
+struct FigReadS { int len, rev, hasN, pos; long long woff; };
 
 struct FigHotU {                     // wave-uniform copies of what the hot loops need
     const int32_t *u_len, *u_aux, *u_pos; const int64_t *u_woff; const uint32_t *packed; const double *insd;
@@ -429,7 +429,7 @@ FIG_D FigHotU fig_hot_uniforms(const FigEng &E) {
 FIG_D FigReadS fig_read_scalars(const FigHotU &U, long long idx) {
     FigReadS r;
     r.len = fig_u(U.u_len[idx]);
-    r.rev = fig_u(U.u_aux[idx]);
+    { const int a = fig_u(U.u_aux[idx]); r.rev = a & 1; r.hasN = (a >> 1) & 1; }
     r.pos = fig_u(U.u_pos[idx]);
     r.woff = fig_u64(U.u_woff[idx]);
     return r;
@@ -507,8 +507,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             for (int i = -(U.L - 1) + wit * U.wsz + lane; i < G; i += T * U.wsz) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
             unsigned long long nplace = 0, nadd = 0;
             // does the read contain an N?  (then the generic chain handles it)
-            bool hasN = false;
-            { int nwm = (rs.len + 31) >> 5; uint32_t any = 0; for (int q = 0; q < nwm; q++) any |= pk[nw2 + q]; hasN = any != 0; }
+            const bool hasN = rs.hasN != 0;
             const int stride = T * U.wsz;
             int o = w.lo + wit * U.wsz + lane;
             if (!hasN && !clipped) {
@@ -826,7 +825,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
         r = fig_u(r);
         if (r >= nU) break;
         const bool active = true;
-        FigReadS rs; rs.len = 0; rs.rev = 0; rs.pos = 0; rs.woff = 0;
+        FigReadS rs; rs.len = 0; rs.rev = 0; rs.hasN = 0; rs.pos = 0; rs.woff = 0;
         FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
         if (active) {
             rs = fig_read_scalars(U, ub + r);
@@ -836,8 +835,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             fig_cdp mt = (fig_cdp)(rs.rev ? U.mt_rev + 2 * (U.L - rs.len) : U.mt_fwd);
             FigBest best; best.v = init; best.o = FIG_NOPOS;
             unsigned long long nplace = 0;
-            bool hasN = false;
-            { int nwm = (rs.len + 31) >> 5; uint32_t any = 0; for (int q = 0; q < nwm; q++) any |= pk[nw2 + q]; hasN = any != 0; }
+            const bool hasN = rs.hasN != 0;
             const int stride = T * U.wsz;
             int o = w.lo + wit * U.wsz + lane;
             if (!hasN) {

@@ -125,7 +125,14 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             for (int64_t r = r0; r < r0 + n; r++) {
                 int len = (int)(b->u_seq_off[r + 1] - b->u_seq_off[r]);
                 if (len > FIG_MAX_READLEN || len > m->max_read_length || len < 1) return FIG_EUNSUP;
-                K.u_pos.push_back(b->u_anchor_pos[r]); K.u_aux.push_back(b->u_is_reverse[r] ? 1 : 0); K.u_len.push_back(len);
+                K.u_pos.push_back(b->u_anchor_pos[r]);
+                {   // aux: bit 0 = mate was reverse-complemented, bit 1 = the read has a base outside ACGT (generic chain)
+                    int hasN = 0;
+                    const char *rs_ = b->u_seq + b->u_seq_off[r];
+                    for (int q = 0; q < len; q++) if (code_of(rs_[q]) > 3) { hasN = 1; break; }
+                    K.u_aux.push_back((b->u_is_reverse[r] ? 1 : 0) | (hasN << 1));
+                }
+                K.u_len.push_back(len);
                 K.u_woff.push_back((int64_t)K.packed.size());
                 pack_read(b->u_seq + b->u_seq_off[r], len, K.packed);
             }
