@@ -182,3 +182,25 @@ def test_gpu_work_counters_match_oracle(seed, tmp_path):
     from tools.fuzz_ref import mk
     from tools.compare_emu import run_one
     assert run_one(mk(seed), str(tmp_path), exe=util.FIGFILL, verbose=False, trace=True)
+
+
+def test_near_cap_read_counts_match_oracle(tmp_path):
+    """Gaps at the reference's 3000-reads-per-gap cap (Figbird.cpp:5763), one in the 512-thread LDS class and one in the
+    L2-resident-table class (>1216 columns): bytes equal the oracle's."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=1.0e6)
+    eng, mc = _bench_engine(spec)
+    batch, _ = synth.make_bench_batch(99, 2, spec, gap_lengths=np.array([450, 1500]))
+    assert int(np.diff(batch.u_read_off).max()) > 2500
+    res = eng.fill(batch)
+    eng.close()
+    sample = [0, 1]
+    paths = synth.write_batch_subset(batch, sample, mc, str(tmp_path / "cpu"), spec)
+    case_args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
+                 "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
+    r = util.run([util.ORACLE, "fillgaps"] + case_args, str(tmp_path), timeout=900)
+    assert r.returncode == 0, r.stderr
+    lines = util.read(paths["tmp"] + "gapout.txt").splitlines()
+    for k, g in enumerate(paths["gap_order"]):
+        f = lines[k].split("\t")
+        assert int(f[4]) == int(res.filled_len[g]), f"gap {g}"
+        assert (f[5] if len(f) > 5 else "") == res.strings[g], f"gap {g}"
