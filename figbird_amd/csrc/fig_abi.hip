@@ -358,6 +358,7 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
     dm.max_insert = m->max_insert_size;
     for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
+    dm.fmm_up = fig_model_fmm(m);
     dm.e = d + o_e; dm.ome = d + o_pairs; dm.m3 = d + o_m3; dm.insd = d + o_insd; dm.qtab = d + o_q;
     dm.ome1 = d + o_ome;
     ctx->have_model = true;

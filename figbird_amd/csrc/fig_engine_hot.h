@@ -811,6 +811,28 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int nst = nci_lds ? ncl : cg;             // row stride of the pile-up
     for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) nl[j * nst + x] = 0;
     if (E.tid == 0) S.mle_next = 0;
+    // Mismatch filter: the consensus codes of the extended columns packed 16 per word (kc: 2-bit code, kn: bit 2i set
+    // when column i is N/outside), so that counting the mismatches of a whole read against a placement is ~len/16 xor +
+    // popcount steps.  A match factor is <= 1 and a mismatch factor <= fmm_up, so a placement with m mismatches has a
+    // product <= fmm_up^m: once a running maximum is known, placements with too many mismatches are out without a
+    // single FP64 operation, and the few others are evaluated one by one (fig_mle_serial).
+    const int kwords = (ncolE + 15) / 16 + 16;       // + a read's worth of words past the last column (read as N)
+    const long long nci_doubles = nci_lds ? (5LL * ncl + 1) / 2 + 1 : 0;
+    const double fmm = fig_uptr(E.M)->fmm_up;
+    const bool use_kf = LDS && fmm < 0.5 && (long long)nrows * U.Wcap - fb_doubles - nci_doubles >= kwords + 1;
+    uint32_t *kc = (uint32_t *)(fig_w_ptr<LDS>(E) + fb_doubles + nci_doubles), *kn = kc + kwords;
+    if (use_kf) {
+        int ncb = gl + 2 * xoff; if (ncb > ncolE) ncb = ncolE;
+        for (int wd = E.tid; wd < kwords; wd += E.nt) {
+            uint32_t c2 = 0, n2 = 0;
+            for (int q = 0; q < 16; q++) {
+                const int i = wd * 16 + q;
+                const int from = i < ncb ? fig_from_code(E, i - xoff, gl, wl, wr) : 4;
+                if (from >= 0 && from < 4) c2 |= (uint32_t)from << (2 * q); else n2 |= 1u << (2 * q);
+            }
+            kc[wd] = c2; kn[wd] = n2;
+        }
+    }
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
@@ -872,6 +894,71 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     nplace += (va_ok ? 1 : 0) + (vb_ok ? 1 : 0);
                     // out-of-window lanes read inside the table (clamped) and are ignored
                     const int xa = (va_ok ? oa : w.hi) + xoff, xb = (vb_ok ? ob : w.hi) + xoff;
+                    if (use_kf && use_serial) {
+                        // mismatches of the whole read at both placements of the lane, counted in two stages: after the first
+                        // 32 bases nearly every wrong placement already exceeds the cut, and the round is dropped right there
+                        int mma = 0, mmb_ = 0;
+                        const bool have_cut = bound > 1e-290;
+                        const int mcut0 = have_cut ? (int)(fig_log(bound) / fig_log(fmm)) + 2 : 0x7fffffff;
+                        bool dropped = false;
+                        {
+                            const int wia = xa >> 4, sha = (xa & 15) * 2, wib = xb >> 4, shb = (xb & 15) * 2;
+                            uint32_t pca = kc[wia], pna = kn[wia], pcb = kc[wib], pnb = kn[wib];
+                            const int nwr = (rs.len + 15) >> 4;
+                            for (int wq = 0; wq < nwr; wq++) {
+                                const uint32_t rw = pk[wq];
+                                const int rem = rs.len - wq * 16;
+                                const uint32_t lm = rem >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - rem)));
+                                const uint32_t nca = kc[wia + wq + 1], nna = kn[wia + wq + 1], ncb = kc[wib + wq + 1], nnb = kn[wib + wq + 1];
+                                const uint32_t cva = sha ? (pca >> sha) | (nca << (32 - sha)) : pca, nva = sha ? (pna >> sha) | (nna << (32 - sha)) : pna;
+                                const uint32_t cvb = shb ? (pcb >> shb) | (ncb << (32 - shb)) : pcb, nvb = shb ? (pnb >> shb) | (nnb << (32 - shb)) : pnb;
+                                const uint32_t da = cva ^ rw, db = cvb ^ rw;
+                                mma += __builtin_popcount(((da | (da >> 1)) | nva) & lm);
+                                mmb_ += __builtin_popcount(((db | (db >> 1)) | nvb) & lm);
+                                pca = nca; pna = nna; pcb = ncb; pnb = nnb;
+                                if (wq == 1 && have_cut && !fig_wave_any((va_ok && mma < mcut0) || (vb_ok && mmb_ < mcut0))) { dropped = true; break; }
+                            }
+                        }
+                        if (dropped) { FIG_TICK(E, 17); continue; }
+                        if (!(bound > init)) {
+                            // no maximum yet: evaluate the placement with the fewest mismatches of this round first
+                            int best_mm = va_ok ? mma : 0x7fffffff, best_o = va_ok ? oa : FIG_NOPOS;
+                            if (vb_ok && mmb_ < best_mm) { best_mm = mmb_; best_o = ob; }
+                            FigBest bm; bm.v = -(double)best_mm; bm.o = best_o;          // larger v = fewer mismatches; ties -> smaller o
+                            bm = fig_wave_best(E, bm);
+                            const int o1 = fig_u(bm.o);
+                            if (o1 != FIG_NOPOS) {
+                                const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, o1 + xoff, fbuf, lane, U.wsz);
+                                if (v > init) { FigBest y; y.v = v; y.o = o1; ub = fig_best_merge(ub, y); }
+                                if (v > bound) bound = v;
+                            }
+                        }
+                        // (the bound must sit well above the denormal range: down there FP products stop shrinking -- one ulp
+                        // times 0.99 rounds back to one ulp -- and fmm^m no longer bounds them; such rounds take the chain)
+                        if (bound > 1e-290) {
+                            // mismatch counts m with fmm^m < bound cannot reach the maximum: m >= mcut (two steps of slack
+                            // cover the rounding of the logarithms)
+                            const int mcut = have_cut ? mcut0 : (int)(fig_log(bound) / fig_log(fmm)) + 2;
+                            unsigned long long sa = fig_ballot(va_ok && mma < mcut), sb = fig_ballot(vb_ok && mmb_ < mcut);
+                            if (fig_popc64(sa) + fig_popc64(sb) <= 12) {
+                                const int base_a = obase + 2 * rr * stride;
+                                for (int half = 0; half < 2; half++) {
+                                    unsigned long long m = half ? sb : sa;
+                                    while (m) {
+                                        int bit = 0; { unsigned long long t = m; while (!(t & 1)) { t >>= 1; bit++; } }
+                                        m &= m - 1;
+                                        const int os = base_a + bit + (half ? stride : 0);
+                                        if (os == ub.o) continue;                   // already evaluated
+                                        const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                                        if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
+                                        if (v > bound) bound = v;
+                                    }
+                                }
+                                FIG_TICK(E, 17);
+                                continue;
+                            }
+                        }
+                    }
                     double qa = 1, qb = 1;
                     unsigned long long ma = 0, mb = 0;
 #ifdef FIG_EMU

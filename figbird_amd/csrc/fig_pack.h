@@ -66,6 +66,18 @@ static void pack_read(const char *s, int len, std::vector<uint32_t> &out) {
     }
 }
 
+// Upper bound of the MLE pass's mismatch factors e[k] * errorTypeProbs[from][to] (from != to; from = 4 is an N column):
+// what the k-mer prefilter of fig_hot_mle raises to the number of mismatches.  Rounded up a little so that products
+// of it stay upper bounds in floating point.
+static inline double fig_model_fmm(const fig_model *m) {
+    double emax = 0, tmax = 0;
+    for (int k = 0; k < m->max_read_length; k++) emax = std::max(emax, m->error_pos_dist[k]);
+    for (int from = 0; from < 5; from++) for (int to = 0; to < 4; to++) if (from != to) tmax = std::max(tmax, m->error_type_probs[from * 5 + to]);
+    double f = emax * tmax * (1.0 + 1e-9);
+    if (!(f > 0)) f = 1.0;
+    return f < 1.0 ? f : 1.0;
+}
+
 struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end; };
 
 struct FigPacked {

@@ -27,6 +27,7 @@ struct FigDevModel {
     const double *m3;                // 1 - errorPosDist[k] - inPosDist[k] - delPosDist[k]
     const double *insd;              // insertLengthDistSmoothed[max_insert]
     const double *qtab;              // [256] pow(10, -(c-33)/10.0)   (qualityFilter, Figbird.cpp:1791-1792)
+    double fmm_up;                   // upper bound of any MLE mismatch factor e[k]*T[from][to], from != to (k-mer prefilter)
 };
 
 struct FigDevGap {

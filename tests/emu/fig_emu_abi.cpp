@@ -55,6 +55,7 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     dm.read_length = m->read_length; dm.neg_overlap = m->neg_overlap; dm.partial_len = m->partial_len; dm.unm_limit = m->unm_limit;
     dm.max_insert = m->max_insert_size;
     for (int i = 0; i < 25; i++) dm.T[i] = m->error_type_probs[i];
+    dm.fmm_up = fig_model_fmm(m);
     ctx->pairs.assign((size_t)8 * L, 0.0);
     for (int k = 0; k < L; k++) {
         ctx->pairs[2 * k] = ctx->ome[k]; ctx->pairs[2 * k + 1] = ctx->e[k];
