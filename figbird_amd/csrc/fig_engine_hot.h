@@ -819,6 +819,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int kwords = (ncolE + 15) / 16 + 16;       // + a read's worth of words past the last column (read as N)
     const long long nci_doubles = nci_lds ? (5LL * ncl + 1) / 2 + 1 : 0;
     const double fmm = fig_uptr(E.M)->fmm_up;
+    const double lfmm = fig_log(fmm < 1.0 ? fmm : 0.5);
     const bool use_kf = LDS && fmm < 0.5 && (long long)nrows * U.Wcap - fb_doubles - nci_doubles >= kwords + 1;
     uint32_t *kc = (uint32_t *)(fig_w_ptr<LDS>(E) + fb_doubles + nci_doubles), *kn = kc + kwords;
     if (use_kf) {
@@ -873,6 +874,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 // bound; those are then finished one by one, again serially.  Nothing else can be the maximum (or tie it),
                 // so value and arg-max are exactly those of the full scan.
                 double bound = init;
+                int mcut_cur = 0x7fffffff; double mcut_for = init;   // mismatch cut of the filter, recomputed when bound moves
                 FigBest ub; ub.v = init; ub.o = FIG_NOPOS;         // wave-uniform best of the serial evaluations
                 FigSerLane SL;
                 if (use_serial) fig_mle_serial_prep(SL, pk, mt, rs.len, lane, U.wsz);
@@ -899,17 +901,24 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                         // 32 bases nearly every wrong placement already exceeds the cut, and the round is dropped right there
                         int mma = 0, mmb_ = 0;
                         const bool have_cut = bound > 1e-290;
-                        const int mcut0 = have_cut ? (int)(fig_log(bound) / fig_log(fmm)) + 2 : 0x7fffffff;
+                        if (have_cut && bound != mcut_for) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                        const int mcut0 = have_cut ? mcut_cur : 0x7fffffff;
                         bool dropped = false;
                         {
                             const int wia = xa >> 4, sha = (xa & 15) * 2, wib = xb >> 4, shb = (xb & 15) * 2;
                             uint32_t pca = kc[wia], pna = kn[wia], pcb = kc[wib], pnb = kn[wib];
+                            // the words of the first stage are fetched together (one LDS latency instead of two)
+                            const uint32_t fa1 = kc[wia + 1], ga1 = kn[wia + 1], fb1 = kc[wib + 1], gb1 = kn[wib + 1];
+                            const uint32_t fa2 = kc[wia + 2], ga2 = kn[wia + 2], fb2 = kc[wib + 2], gb2 = kn[wib + 2];
                             const int nwr = (rs.len + 15) >> 4;
                             for (int wq = 0; wq < nwr; wq++) {
                                 const uint32_t rw = pk[wq];
                                 const int rem = rs.len - wq * 16;
                                 const uint32_t lm = rem >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - rem)));
-                                const uint32_t nca = kc[wia + wq + 1], nna = kn[wia + wq + 1], ncb = kc[wib + wq + 1], nnb = kn[wib + wq + 1];
+                                uint32_t nca, nna, ncb, nnb;
+                                if (wq == 0) { nca = fa1; nna = ga1; ncb = fb1; nnb = gb1; }
+                                else if (wq == 1) { nca = fa2; nna = ga2; ncb = fb2; nnb = gb2; }
+                                else { nca = kc[wia + wq + 1]; nna = kn[wia + wq + 1]; ncb = kc[wib + wq + 1]; nnb = kn[wib + wq + 1]; }
                                 const uint32_t cva = sha ? (pca >> sha) | (nca << (32 - sha)) : pca, nva = sha ? (pna >> sha) | (nna << (32 - sha)) : pna;
                                 const uint32_t cvb = shb ? (pcb >> shb) | (ncb << (32 - shb)) : pcb, nvb = shb ? (pnb >> shb) | (nnb << (32 - shb)) : pnb;
                                 const uint32_t da = cva ^ rw, db = cvb ^ rw;
@@ -938,7 +947,8 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                         if (bound > 1e-290) {
                             // mismatch counts m with fmm^m < bound cannot reach the maximum: m >= mcut (two steps of slack
                             // cover the rounding of the logarithms)
-                            const int mcut = have_cut ? mcut0 : (int)(fig_log(bound) / fig_log(fmm)) + 2;
+                            if (bound != mcut_for) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                            const int mcut = mcut_cur;
                             unsigned long long sa = fig_ballot(va_ok && mma < mcut), sb = fig_ballot(vb_ok && mmb_ < mcut);
                             if (fig_popc64(sa) + fig_popc64(sb) <= 12) {
                                 const int base_a = obase + 2 * rr * stride;
