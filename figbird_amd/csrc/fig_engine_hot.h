@@ -57,6 +57,30 @@ FIG_D long long fig_u64(long long w) {
 #endif
 }
 
+// Wave maximum through DPP row shifts / broadcasts (gfx9 row_shr:1,2,4,8 then row_bcast:15 and :31): three vector
+// instructions per step and no LDS traffic, against three ds_bpermute per step of the shuffle form.  Result in every lane.
+FIG_D double fig_wave_max_dpp(double v) {
+#ifdef FIG_EMU
+    return v;
+#else
+    const double ident = -FIG_DBL_MAX * 2.0;          // -inf: lanes that receive nothing keep their own value through max
+#define FIG_DPP_STEP(ctrl, rmask) do { \
+        long long b_; memcpy(&b_, &v, 8); long long i_; memcpy(&i_, &ident, 8); \
+        int lo_ = __builtin_amdgcn_update_dpp((int)(i_ & 0xffffffffLL), (int)(b_ & 0xffffffffLL), ctrl, rmask, 0xf, false); \
+        int hi_ = __builtin_amdgcn_update_dpp((int)(i_ >> 32), (int)(b_ >> 32), ctrl, rmask, 0xf, false); \
+        long long o_ = ((long long)hi_ << 32) | (unsigned int)lo_; double y_; memcpy(&y_, &o_, 8); \
+        v = y_ > v ? y_ : v; } while (0)
+    FIG_DPP_STEP(0x111, 0xf); FIG_DPP_STEP(0x112, 0xf); FIG_DPP_STEP(0x114, 0xf); FIG_DPP_STEP(0x118, 0xf);
+    FIG_DPP_STEP(0x142, 0xa); FIG_DPP_STEP(0x143, 0xc);
+#undef FIG_DPP_STEP
+    long long b2; memcpy(&b2, &v, 8);
+    const unsigned int l = (unsigned int)__builtin_amdgcn_readlane((int)(b2 & 0xffffffffLL), 63), h = (unsigned int)__builtin_amdgcn_readlane((int)(b2 >> 32), 63);
+    b2 = (long long)(((unsigned long long)h << 32) | l);
+    memcpy(&v, &b2, 8);
+    return v;
+#endif
+}
+
 FIG_D double fig_wave_max(double v) {
 #ifdef FIG_EMU
     return v;
@@ -589,8 +613,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 nplace++; nadd += fig_ovl(o, rs.len, G);
             }
             E.flops += 4ULL * nplace * (unsigned long long)rs.len + nadd;
-            best = fig_wave_best(E, best);
-            if (lane == 0) { S.wv_v[wave] = best.v; S.wv_o[wave] = best.o; }
+            // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do
+            { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
+              if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? 0 : FIG_NOPOS; } }
             if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;
         }
         FIG_TICK(E, 11);
