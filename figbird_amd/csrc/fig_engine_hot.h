@@ -914,7 +914,69 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     }
                 }
                 FIG_TICK(E, 15);
-                for (int q = 0; q < nrounds; q++) {
+                // Fast path (a usable maximum from the hint): one sweep over all placements, one per lane and step, judging
+                // each by the mismatches of its first 32 bases; the few that pass get the whole-read count (lanes = words
+                // of the read) and, if that passes too, the one-by-one evaluation.
+                bool swept = false;
+                if (use_kf && use_serial && bound > 1e-290 && rs.len >= 32) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                // (only with a sharp cut: 32 random bases show ~24 mismatches, so a cut above ~18 would let too many through)
+                if (use_kf && use_serial && bound > 1e-290 && rs.len >= 32 && mcut_cur <= 18) {
+                    swept = true;
+                    const uint32_t rw0 = pk[0], rw1 = pk[1];
+                    const int nwr = (rs.len + 15) >> 4;
+                    const int lwq = lane < nwr ? lane : nwr - 1;                 // the read word this lane owns in the full count
+                    const uint32_t rwl = pk[lwq];
+                    const int reml = rs.len - lwq * 16;
+                    const uint32_t lml = lane < nwr ? (reml >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - reml)))) : 0u;
+                    for (int ob0 = w.lo; ob0 <= w.hi; ob0 += U.wsz) {
+                        const int o1 = ob0 + lane;
+                        const bool ok1 = o1 <= w.hi;
+                        if (ok1) nplace++;
+                        const int xe = (ok1 ? o1 : w.hi) + xoff;
+                        const int wi = xe >> 4, sh = (xe & 15) * 2;
+                        const uint32_t c0 = kc[wi], c1 = kc[wi + 1], c2 = kc[wi + 2], n0 = kn[wi], n1 = kn[wi + 1], n2 = kn[wi + 2];
+                        const uint32_t cv0 = sh ? (c0 >> sh) | (c1 << (32 - sh)) : c0, nv0 = sh ? (n0 >> sh) | (n1 << (32 - sh)) : n0;
+                        const uint32_t cv1 = sh ? (c1 >> sh) | (c2 << (32 - sh)) : c1, nv1 = sh ? (n1 >> sh) | (n2 << (32 - sh)) : n1;
+                        const uint32_t d0 = cv0 ^ rw0, d1 = cv1 ^ rw1;
+                        const int mm = __builtin_popcount(((d0 | (d0 >> 1)) | nv0) & 0x55555555u) + __builtin_popcount(((d1 | (d1 >> 1)) | nv1) & 0x55555555u);
+                        if (bound != mcut_for) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                        unsigned long long cm = fig_ballot(ok1 && mm < mcut_cur);
+                        while (cm) {
+                            int bit = 0; { unsigned long long t = cm; while (!(t & 1)) { t >>= 1; bit++; } }
+                            cm &= cm - 1;
+                            const int os = ob0 + bit;
+                            if (os == ub.o) continue;                             // the hint, already evaluated
+                            // whole-read mismatch count of placement os: lane q handles word q, then a sum over the lanes
+                            const int xs = os + xoff + lwq * 16;
+                            const int wj = xs >> 4, sj = (xs & 15) * 2;
+                            const uint32_t e0 = kc[wj], e1 = kc[wj + 1], f0 = kn[wj], f1 = kn[wj + 1];
+                            const uint32_t ev = sj ? (e0 >> sj) | (e1 << (32 - sj)) : e0, fv = sj ? (f0 >> sj) | (f1 << (32 - sj)) : f0;
+                            const uint32_t dd = ev ^ rwl;
+                            int mml = __builtin_popcount(((dd | (dd >> 1)) | fv) & lml);
+                            int mmf = 0;
+#ifdef FIG_EMU
+                            mmf = 0;
+                            for (int q2 = 0; q2 < nwr; q2++) {
+                                const int xq = os + xoff + q2 * 16; const int wq2 = xq >> 4, sq2 = (xq & 15) * 2;
+                                const uint32_t g0 = kc[wq2], g1 = kc[wq2 + 1], h0 = kn[wq2], h1 = kn[wq2 + 1];
+                                const uint32_t gv = sq2 ? (g0 >> sq2) | (g1 << (32 - sq2)) : g0, hv = sq2 ? (h0 >> sq2) | (h1 << (32 - sq2)) : h0;
+                                const uint32_t dq = gv ^ pk[q2]; const int remq = rs.len - q2 * 16;
+                                const uint32_t lq = remq >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - remq)));
+                                mmf += __builtin_popcount(((dq | (dq >> 1)) | hv) & lq);
+                            }
+                            (void)mml;
+#else
+                            for (int q2 = 0; q2 < nwr; q2++) mmf += __builtin_amdgcn_readlane(mml, q2);
+#endif
+                            if (mmf >= mcut_cur) continue;
+                            const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                            if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
+                            if (v > bound) { bound = v; mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                        }
+                    }
+                    FIG_TICK(E, 17);
+                }
+                for (int q = 0; q < nrounds && !swept; q++) {
                     int rr = r0 + q; if (rr >= nrounds) rr -= nrounds;
                     const int oa = obase + lane + 2 * rr * stride, ob = oa + stride;
                     const bool va_ok = oa <= w.hi, vb_ok = ob <= w.hi;
