@@ -94,7 +94,8 @@ FIG_D void fig_accumulate_columns(FigEng &E, int len, int lo, int hi, int G) {
     int cg = E.capG;
     int xlo = lo < 0 ? 0 : lo;                    // first column any placement can reach
     int xhi = hi + len - 1; if (xhi > G - 1) xhi = G - 1;
-    for (int x = xlo + E.tid; x <= xhi; x += E.nt) {
+    for (int x = E.tid; x <= xhi; x += E.nt) {      // column -> thread mapping independent of the read: no barrier needed between reads
+        if (x < xlo) continue;
         int o0 = x - (len - 1); if (o0 < lo) o0 = lo;
         int o1 = x; if (o1 > hi) o1 = hi;
         if (o0 > o1) continue;
@@ -608,26 +609,42 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         int nproc = np < FIG_READ_CAP ? np : FIG_READ_CAP;           // reads 0..2999 (:3121-3122)
         const FigDevReads &PR = E.B->p;
         long long pb = E.g->pBase;
-        for (int p = 0; p < nproc; p++) {
-            fig_stage_read(E, PR, pb + p);
-            FIG_SYNC();
-            int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
-            int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
-            FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
-            FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
-            for (int o = w.lo + E.tid; o <= w.hi; o += E.nt) {
-                double t = fig_estep_chain(E, 1.0, o, len, j0, j1, 0, G, left, right);
-                t = fig_log(t);
-                if (t > best.v) { best.v = t; best.o = o; }
-                E.wbuf[o - w.lo] = fig_pow10(t);
-                E.flops += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(o, len, G);
+        // E-step over the partial reads (:3082-3264): one read per wave (a read has at most len-1 placements), up to `nrow`
+        // reads per chunk; each wave stages its read's codes and its weight row, then all lanes add the chunk's rows
+        // into the gap columns read by read (the reference's order), and lane 0 adds the per-read maxima in read order.
+        unsigned char *const rb_keep = E.rb; double *const wbuf_keep = E.wbuf;
+        int nrow = E.nw < E.nteams ? E.nw : E.nteams; if (nrow > FIG_PLB_TEAMS) nrow = FIG_PLB_TEAMS; if (nrow < 1) nrow = 1;
+        for (int p0 = 0; p0 < nproc; p0 += nrow) {
+            const int nr = nproc - p0 < nrow ? nproc - p0 : nrow;
+            if (E.wave < nr) {
+                const int p = p0 + E.wave;
+                unsigned char *rbw = (unsigned char *)E.plb + E.wave * 256;
+                const int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
+                { const long long woff = PR.woff[pb + p]; for (int j = E.lane; j < len; j += E.wsz) rbw[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j); }
+                E.rb = rbw;
+                double *wr = wbuf_keep + (long long)E.wave * E.Wcap;
+                int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
+                FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
+                FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+                for (int o = w.lo + E.lane; o <= w.hi; o += E.wsz) {
+                    double t = fig_estep_chain(E, 1.0, o, len, j0, j1, 0, G, left, right);
+                    t = fig_log(t);
+                    if (t > best.v) { best.v = t; best.o = o; }
+                    wr[o - w.lo] = fig_pow10(t);
+                    E.flops += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(o, len, G);
+                }
+                best = fig_wave_best(E, best);
+                if (E.lane == 0) { S.wv_v[E.wave] = best.v; S.wv_o[E.wave] = best.o; S.tm_lo[E.wave] = w.lo; S.tm_hi[E.wave] = w.hi; S.tm_len[E.wave] = len; }
             }
-            best = fig_block_best(E, best);
             FIG_SYNC();
-            fig_accumulate_columns(E, len, w.lo, w.hi, G);
-            if (E.tid == 0 && best.o != FIG_NOPOS) maxLikelihood += best.v;
+            for (int t = 0; t < nr; t++) {
+                E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * E.Wcap;
+                fig_accumulate_columns(E, S.tm_len[t], S.tm_lo[t], S.tm_hi[t], G);
+                if (E.tid == 0 && S.wv_o[t] != FIG_NOPOS) maxLikelihood += S.wv_v[t];
+            }
             FIG_SYNC();
         }
+        E.rb = rb_keep; E.wbuf = wbuf_keep;
         // ---- MLE pass over the partial reads (:3267-3523)
         int prc = S.partial_read_count;
         for (int i = E.tid; i < prc; i += E.nt) {
@@ -637,30 +654,33 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         fig_compute_sequence(E, 0, 0);
         for (int x = E.tid; x < S.ncols; x += E.nt) { E.gs[x] = E.scr.cons[x]; for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = 0; }
         FIG_SYNC();
-        for (int p = 0; p < nproc; p++) {
-            fig_stage_read(E, PR, pb + p);
-            FIG_SYNC();
-            int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
+        // one read per wave, no workgroup barrier inside the loop (the per-read results are independent)
+        for (int p = E.wave; p < nproc; p += E.nw) {
+            unsigned char *rbw = (unsigned char *)E.plb + (E.wave % FIG_PLB_TEAMS) * 256;
+            const int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
+            { const long long woff = PR.woff[pb + p]; for (int j = E.lane; j < len; j += E.wsz) rbw[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j); }
+            E.rb = rbw;
             int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
             FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
             FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
-            for (int o = w.lo + E.tid; o <= w.hi; o += E.nt) {
+            for (int o = w.lo + E.lane; o <= w.hi; o += E.wsz) {
                 double t = fig_mle_chain(E, o, len, j0, j1, 0, G, left, right);
                 if (t > best.v) { best.v = t; best.o = o; }
                 E.flops += (unsigned long long)(j1 - j0);
             }
-            best = fig_block_best(E, best);
-            if (E.tid == 0 && p < prc) {
+            best = fig_wave_best(E, best);
+            if (E.lane == 0 && p < prc) {
                 int o = best.o == FIG_NOPOS ? -left : best.o;
                 double temp_log_val = -fig_log10(best.v);
                 if (temp_log_val < M.cutoff) {
-                    S.valid_count++;
+                    fig_atomic_add_i32(&S.valid_count, 1);
                     E.scr.pflag[p * 2 + 1] = o;
                     if (G == G0) { E.scr.ppos_org[p * 3] = 1; E.scr.ppos_org[p * 3 + 1] = o; E.scr.ppos_org[p * 3 + 2] = len; }
-                } else { S.invalid_count++; E.scr.pflag[p * 2] = 0; }
+                } else { fig_atomic_add_i32(&S.invalid_count, 1); E.scr.pflag[p * 2] = 0; }
             }
-            FIG_SYNC();
         }
+        E.rb = rb_keep;
+        FIG_SYNC();
         if (E.tid == 0) {
             int ret_val[2] = {0, 0};
             fig_detect_overlap(E, E.scr.pflag, 2, G, ret_val, 8);
