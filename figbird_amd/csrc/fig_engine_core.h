@@ -654,6 +654,9 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         fig_compute_sequence(E, 0, 0);
         for (int x = E.tid; x < S.ncols; x += E.nt) { E.gs[x] = E.scr.cons[x]; for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = 0; }
         FIG_SYNC();
+        // match/mismatch table over the extended columns (overlays the {P,Q} table, which the next computeProbsGap rebuilds)
+        fig_build_mle_table(E, G, left, right);          // ends with a barrier
+        const double *Ctab = (const double *)E.pq;
         // one read per wave, no workgroup barrier inside the loop (the per-read results are independent)
         for (int p = E.wave; p < nproc; p += E.nw) {
             unsigned char *rbw = (unsigned char *)E.plb + (E.wave % FIG_PLB_TEAMS) * 256;
@@ -664,7 +667,16 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
             FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
             for (int o = w.lo + E.lane; o <= w.hi; o += E.wsz) {
-                double t = fig_mle_chain(E, o, len, j0, j1, 0, G, left, right);
+                double t = 1;
+                {   // fig_mle_chain through the table: factor = m3[k] on a match, e[k]*T[from][to] otherwise (k = j: forward reads)
+                    const double *e_ = E.M->e, *m3_ = E.M->m3;
+                    const double *cc = Ctab + o + E.xoff;
+                    for (int j = j0; j < j1; j++) {
+                        const double c = cc[(long long)rbw[j] * E.ncolE + j];
+                        const double f = e_[j] * c;
+                        t *= (c < 0 ? m3_[j] : f);
+                    }
+                }
                 if (t > best.v) { best.v = t; best.o = o; }
                 E.flops += (unsigned long long)(j1 - j0);
             }
