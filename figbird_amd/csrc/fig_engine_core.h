@@ -626,8 +626,29 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
                 FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
                 FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+                // reads without N whose placements stay inside the flank window take the table/scalar-load form of the chain
+                bool slow = left < E.xoff;
+                { bool n = false; for (int j = E.lane; j < len; j += E.wsz) n = n || rbw[j] > 3; slow = slow || fig_wave_any(n); }
+                const FigPQ *PQt = fig_pq_ptr<LDS>(E);
+                fig_cu32p pkr = (fig_cu32p)(fig_uptr(E.B->packed) + fig_u64(PR.woff[pb + p]));
+                fig_cdp ktf = (fig_cdp)fig_uptr(E.kt_fwd);
+                const int ncolE_u = fig_u(E.ncolE), xoff_u = fig_u(E.xoff), j0u = fig_u(j0), j1u = fig_u(j1);
                 for (int o = w.lo + E.lane; o <= w.hi; o += E.wsz) {
-                    double t = fig_estep_chain(E, 1.0, o, len, j0, j1, 0, G, left, right);
+                    double t;
+                    if (slow) t = fig_estep_chain(E, 1.0, o, len, j0, j1, 0, G, left, right);
+                    else {
+                        t = 1.0;
+                        const FigPQ *col = PQt + o + xoff_u;
+                        int j = j0u;
+                        for (; j + 4 <= j1u; j += 4) {
+                            FigPQ v[4]; double kk[8];
+#pragma unroll
+                            for (int q = 0; q < 4; q++) { const int jj = j + q; const int b = (int)((pkr[jj >> 4] >> ((jj & 15) * 2)) & 3); v[q] = col[b * ncolE_u + jj]; kk[2 * q] = ktf[2 * jj]; kk[2 * q + 1] = ktf[2 * jj + 1]; }
+#pragma unroll
+                            for (int q = 0; q < 4; q++) t *= (v[q].p * kk[2 * q] + kk[2 * q + 1] * v[q].q);
+                        }
+                        for (; j < j1u; j++) { const int b = (int)((pkr[j >> 4] >> ((j & 15) * 2)) & 3); const FigPQ v = col[b * ncolE_u + j]; t *= (v.p * ktf[2 * j] + ktf[2 * j + 1] * v.q); }
+                    }
                     t = fig_log(t);
                     if (t > best.v) { best.v = t; best.o = o; }
                     wr[o - w.lo] = fig_pow10(t);
@@ -645,6 +666,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             FIG_SYNC();
         }
         E.rb = rb_keep; E.wbuf = wbuf_keep;
+        FIG_TICK(E, 4);
         // ---- MLE pass over the partial reads (:3267-3523)
         int prc = S.partial_read_count;
         for (int i = E.tid; i < prc; i += E.nt) {
@@ -693,6 +715,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         }
         E.rb = rb_keep;
         FIG_SYNC();
+        FIG_TICK(E, 5);
         if (E.tid == 0) {
             int ret_val[2] = {0, 0};
             fig_detect_overlap(E, E.scr.pflag, 2, G, ret_val, 8);
