@@ -156,6 +156,7 @@ def main():
     ach = flops_all / world / max(ksec, 1e-12) / 1e12 if world > 1 else flops_all / max(ksec, 1e-12) / 1e12
     alg_bytes = up["packed_bytes"] * args.steps + filled
     out["roofline"] = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_NOFMA_PEAK_TFLOPS,
+                       "peak_note": "FP64 vector issue without FMA (256 CU x 4 SIMD x 16 lanes x 2.4 GHz): multiply and add must stay unfused for bit-exactness", "peak_with_fma": 2 * FP64_NOFMA_PEAK_TFLOPS, "frac_of_fma_peak": ach / (2 * FP64_NOFMA_PEAK_TFLOPS),
                        "traffic": None, "kernel": "fig_eval_kernel<LDS_TAB,NT> (+ fig_begin/replay/end: all launches of one fill, 3 class lanes)", "launches_per_step": st["n_launches"], "kernel_ms_per_step": kernel_ms_avg / max(args.steps, 1),
                        "alg_flops_per_step": flops_all / world / max(args.steps, 1), "placeReads_calls_per_step": place_calls / max(args.steps, 1),
                        "hbm": {"achieved": alg_bytes / max(ksec, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
