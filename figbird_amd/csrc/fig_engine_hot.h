@@ -3,19 +3,25 @@
 // 99 % of the reference's time is the two triple loops of placeReads (Figbird.cpp:3530-3689 E-step,
 // :3732-3846 MLE pass): for every read, every placement, every base one FP64 factor.  Mapping:
 //
-//   * reads are dealt to TEAMS of T waves (nteams = nw / T reads in flight per workgroup); inside a
-//     team, lanes = placements (stride 64*T);
-//   * everything that is the same for all placements of a read at chain step j -- the read base
-//     b_j (2-bit packed words), {1-e[k], e[k]} -- is wave-uniform and comes in through SCALAR loads
-//     (constant address space -> s_load_dwordx16, s_bfe), so the vector pipe only sees one LDS read
-//     of {P,Q}[b_j][x] (16 B, conflict-free: lane i reads column o_i + j) and four FP64 ops per step:
-//     t1 = P*(1-e); t2 = e*Q; f = t1+t2; p *= f   (no FMA: -ffp-contract=off, as the x86 reference);
-//   * the per-placement weights land in LDS (wbuf[team][placement]); after a workgroup barrier the
-//     lanes switch to COLUMNS and add the weights that cover their column in exactly the reference's
-//     (read, placement) order -- accumulators stay in registers for the whole E-step (no atomics, so
-//     countsGap is bit-identical to the CPU);
-//   * the MLE pass reuses the table area for C[to][x] = errorTypeProbs[from_x][to] (or -1 = match), so a
-//     step is one 8-byte LDS read + two multiplies; arg-max is "first maximum wins".
+//   E-step (fig_hot_estep)
+//   * reads go in chunks of `nteams` (= weight rows that fit in LDS); a TEAM of T = nw/nteams waves takes one read,
+//     lanes = placements, two per lane (pair rounds; the tail of a read is split evenly over the team's waves);
+//   * everything that is the same for all placements of a read at chain step j -- the read base b_j (2-bit packed
+//     words), {1-e[k], e[k]} -- is wave-uniform and comes in through SCALAR loads (constant address space ->
+//     s_load_dwordx16, s_bfe), so the vector pipe only sees one LDS read of {P,Q}[b_j][x] (16 B, conflict-free:
+//     lane i reads column o_i + j; the pair's second placement at a constant offset of the same address) and four
+//     FP64 ops per step: t1 = P*(1-e); t2 = e*Q; f = t1+t2; p *= f   (no FMA: -ffp-contract=off, as the x86
+//     reference); 8-step blocks, the loads of block i+1 issued before the arithmetic of block i;
+//   * the per-placement weights land in LDS (one row per read, zero outside the insert-size window); after a
+//     workgroup barrier the lanes switch to COLUMNS: each wave owns one base and a run of 64-column tiles and adds
+//     the weights that cover its columns in exactly the reference's (read, placement) order -- accumulators stay in
+//     registers for the whole E-step (no atomics, so countsGap is bit-identical to the CPU);
+//   MLE pass (fig_hot_mle)
+//   * reuses the table area for C[to][x] = errorTypeProbs[from_x][to] (or -1 = match); one read per wave, taken
+//     dynamically, no workgroup barrier; exact pruning (all factors <= 1): the previous pass's best placement is
+//     evaluated first (fig_mle_serial), a whole-read mismatch filter on the 2-bit packed consensus (xor + popcount)
+//     then discards every placement that cannot reach that maximum, the few others are evaluated one by one; rounds
+//     the filter cannot judge run the pruned pair chain; arg-max is "first maximum wins".
 #ifndef FIG_ENGINE_HOT_H
 #define FIG_ENGINE_HOT_H
 
