@@ -850,6 +850,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const int kwords = (ncolE + 15) / 16 + 16;       // + a read's worth of words past the last column (read as N)
     const long long nci_doubles = nci_lds ? (5LL * ncl + 1) / 2 + 1 : 0;
     const double fmm = fig_uptr(E.M)->fmm_up;
+    const bool mono = fmm <= 1.0;                     // factors in [0,1]: partial products never grow (else: no pruning at all)
     const double lfmm = fig_log(fmm < 1.0 ? fmm : 0.5);
     const bool use_kf = LDS && fmm < 0.5 && (long long)nrows * U.Wcap - fb_doubles - nci_doubles >= kwords + 1;
     uint32_t *kc = (uint32_t *)(fig_w_ptr<LDS>(E) + fb_doubles + nci_doubles), *kn = kc + kwords;
@@ -1065,9 +1066,9 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     double qa = 1, qb = 1;
                     unsigned long long ma = 0, mb = 0;
 #ifdef FIG_EMU
-                    const int rc = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, bound, use_serial, qa, qb, ma, mb);
+                    const int rc = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb);
 #else
-                    const int rc = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, oa + xoff, 0, va_ok, vb_ok, bound, use_serial, qa, qb, ma, mb);
+                    const int rc = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, oa + xoff, 0, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb);
 #endif
                     FIG_TICK(E, 16);
                     if (rc == 2) {

@@ -73,6 +73,13 @@ static inline double fig_model_fmm(const fig_model *m) {
     double emax = 0, tmax = 0;
     for (int k = 0; k < m->max_read_length; k++) emax = std::max(emax, m->error_pos_dist[k]);
     for (int from = 0; from < 5; from++) for (int to = 0; to < 4; to++) if (from != to) tmax = std::max(tmax, m->error_type_probs[from * 5 + to]);
+    // every exact-pruning argument of the MLE pass needs factors in [0, 1]; a model outside that (possible only with
+    // degenerate training data) is marked with 2.0 and the engine then evaluates every placement in full
+    for (int k = 0; k < m->max_read_length; k++) {
+        const double e = m->error_pos_dist[k], m3 = 1 - e - m->in_pos_dist[k] - m->del_pos_dist[k];
+        if (!(e >= 0 && e <= 1 && m3 >= 0 && m3 <= 1)) return 2.0;
+    }
+    for (int i = 0; i < 25; i++) if (!(m->error_type_probs[i] >= 0 && m->error_type_probs[i] <= 1)) return 2.0;
     double f = emax * tmax * (1.0 + 1e-9);
     if (!(f > 0)) f = 1.0;
     return f < 1.0 ? f : 1.0;
