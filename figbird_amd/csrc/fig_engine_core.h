@@ -688,9 +688,15 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
             FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
             FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+            bool hasn = false;
+            { bool n = false; for (int j = E.lane; j < len; j += E.wsz) n = n || rbw[j] > 3; hasn = fig_wave_any(n); }
+            fig_cu32p pkr = (fig_cu32p)(fig_uptr(E.B->packed) + fig_u64(PR.woff[pb + p]));
+            fig_cdp mtf = (fig_cdp)fig_uptr(E.mt_fwd);
+            const int ncolE_u = fig_u(E.ncolE), xoff_u = fig_u(E.xoff), j0u = fig_u(j0), j1u = fig_u(j1);
             for (int o = w.lo + E.lane; o <= w.hi; o += E.wsz) {
                 double t = 1;
-                {   // fig_mle_chain through the table: factor = m3[k] on a match, e[k]*T[from][to] otherwise (k = j: forward reads)
+                // fig_mle_chain through the table: factor = m3[k] on a match, e[k]*T[from][to] otherwise (k = j: forward reads)
+                if (hasn) {
                     const double *e_ = E.M->e, *m3_ = E.M->m3;
                     const double *cc = Ctab + o + E.xoff;
                     for (int j = j0; j < j1; j++) {
@@ -698,6 +704,17 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                         const double f = e_[j] * c;
                         t *= (c < 0 ? m3_[j] : f);
                     }
+                } else {            // read bases and {m3, e} pairs through scalar loads
+                    const double *cc = Ctab + o + xoff_u;
+                    int j = j0u;
+                    for (; j + 4 <= j1u; j += 4) {
+                        double c[4], kk[8];
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { const int jj = j + q; const int b = (int)((pkr[jj >> 4] >> ((jj & 15) * 2)) & 3); c[q] = cc[b * ncolE_u + jj]; kk[2 * q] = mtf[2 * jj]; kk[2 * q + 1] = mtf[2 * jj + 1]; }
+#pragma unroll
+                        for (int q = 0; q < 4; q++) { const double f = kk[2 * q + 1] * c[q]; t *= (c[q] < 0 ? kk[2 * q] : f); }
+                    }
+                    for (; j < j1u; j++) { const int b = (int)((pkr[j >> 4] >> ((j & 15) * 2)) & 3); const double c = cc[b * ncolE_u + j]; const double f = mtf[2 * j + 1] * c; t *= (c < 0 ? mtf[2 * j] : f); }
                 }
                 if (t > best.v) { best.v = t; best.o = o; }
                 E.flops += (unsigned long long)(j1 - j0);
