@@ -613,7 +613,12 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         // reads per chunk; each wave stages its read's codes and its weight row, then all lanes add the chunk's rows
         // into the gap columns read by read (the reference's order), and lane 0 adds the per-read maxima in read order.
         unsigned char *const rb_keep = E.rb; double *const wbuf_keep = E.wbuf;
-        int nrow = E.nw < E.nteams ? E.nw : E.nteams; if (nrow > FIG_PLB_TEAMS) nrow = FIG_PLB_TEAMS; if (nrow < 1) nrow = 1;
+        // a partial read has at most len-1 <= 199 placements, so its weight row needs 208 doubles, not a full Wcap row:
+        // every wave gets a row whenever the weight area (nteams x Wcap) holds nw such rows
+        int nrow = E.nw < FIG_PLB_TEAMS ? E.nw : FIG_PLB_TEAMS;
+        long long rstride = 208;
+        if ((long long)nrow * rstride > (long long)E.nteams * E.Wcap) { nrow = E.nw < E.nteams ? E.nw : E.nteams; if (nrow > FIG_PLB_TEAMS) nrow = FIG_PLB_TEAMS; rstride = E.Wcap; }
+        if (nrow < 1) nrow = 1;
         for (int p0 = 0; p0 < nproc; p0 += nrow) {
             const int nr = nproc - p0 < nrow ? nproc - p0 : nrow;
             if (E.wave < nr) {
@@ -622,7 +627,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 const int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
                 { const long long woff = PR.woff[pb + p]; for (int j = E.lane; j < len; j += E.wsz) rbw[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j); }
                 E.rb = rbw;
-                double *wr = wbuf_keep + (long long)E.wave * E.Wcap;
+                double *wr = wbuf_keep + (long long)E.wave * rstride;
                 int j0 = (flag1 == 1 || flag1 == 4) ? 2 : 0, j1 = len - ((flag1 == 1 || flag1 == 4) ? 0 : 2);
                 FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
                 FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
@@ -659,7 +664,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             }
             FIG_SYNC();
             for (int t = 0; t < nr; t++) {
-                E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * E.Wcap;
+                E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * rstride;
                 fig_accumulate_columns(E, S.tm_len[t], S.tm_lo[t], S.tm_hi[t], G);
                 if (E.tid == 0 && S.wv_o[t] != FIG_NOPOS) maxLikelihood += S.wv_v[t];
             }
