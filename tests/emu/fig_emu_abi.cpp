@@ -26,7 +26,18 @@ struct fig_ctx {
 };
 
 extern "C" int fig_version(void) { return FIG_ABI_VERSION; }
-extern "C" const char *fig_strerror(int code) { (void)code; return "emu"; }
+extern "C" const char *fig_strerror(int code) {
+    switch (code) {
+        case FIG_OK: return "ok";
+        case FIG_EINVAL: return "invalid argument";
+        case FIG_ENODEV: return "no usable HIP device (libfighip has no CPU path)";
+        case FIG_ENOMEM: return "out of memory";
+        case FIG_EHIP: return "HIP runtime error";
+        case FIG_ENOSPC: return "result string buffer too small";
+        case FIG_EUNSUP: return "input outside the supported envelope";
+        default: return "unknown error";
+    }
+}
 extern "C" int fig_ctx_create(int, fig_ctx **out) { *out = new fig_ctx(); memset(&(*out)->stats, 0, sizeof(fig_stats)); return FIG_OK; }
 extern "C" void fig_ctx_destroy(fig_ctx *c) { delete c; }
 extern "C" void fig_batch_free(fig_ctx *c) { if (c) { c->K = FigPacked(); c->have_batch = false; } }
