@@ -552,6 +552,11 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 double pa_n = 0, pb_n = 0;
                 if (nfull > 0) { const int oa0 = w.lo + wit * U.wsz + lane; pa_n = U.insd[w.tis0 + w.dir * oa0]; pb_n = U.insd[w.tis0 + w.dir * (oa0 + stride)]; }
                 for (int k = 0; k < nfull; k++) {
+#ifndef FIG_EMU
+                    // 8-wave workgroups put waves w and w+4 on one SIMD and the arbiter serves the older one first; taking
+                    // turns at the higher priority, round by round, lets the two finish the phase together
+                    if (U.nw == 8) { if ((k + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
                     const int oa = w.lo + k * 2 * stride + wit * U.wsz + lane, ob = oa + stride;
                     double pa = pa_n, pb = pb_n;
                     if (k + 1 < nfull) { pa_n = U.insd[w.tis0 + w.dir * (oa + 2 * stride)]; pb_n = U.insd[w.tis0 + w.dir * (ob + 2 * stride)]; }
@@ -572,6 +577,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                     FIG_TICK(E, 10);
                     nplace += 2; nadd += fig_ovl(oa, rs.len, G) + fig_ovl(ob, rs.len, G);
                 }
+#ifndef FIG_EMU
+                if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
+#endif
                 {
                     const int tbase = w.lo + nfull * 2 * stride;
                     const int nt = w.hi - tbase + 1;                            // 0 .. 2*stride-1
@@ -638,6 +646,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
         // five per-base accumulators of a column are independent chains; each chain walks that base's positions
         // in descending j (= ascending placement), which is the reference's order (:3603-3611).
         for (int t = 0; t < nteams && c0 + t < nU; t++) {
+#ifndef FIG_EMU
+            if (U.nw == 8) { if ((t + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+#endif
             const int lo = fig_u(S.tm_lo[t]), hi = fig_u(S.tm_hi[t]), len = fig_u(S.tm_len[t]);
             if (hi < lo) continue;
             long long woff = fig_u64(U.u_woff[ub + c0 + t]);
@@ -715,6 +726,9 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             }
 #endif
         }
+#ifndef FIG_EMU
+        if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
+#endif
         FIG_TICK(E, 12);
         FIG_SYNC();
         FIG_TICK(E, 1);
