@@ -65,9 +65,6 @@ FIG_D void fig_persist_of(const FigDevBatch &B, const FigDevGap &g, FigPersist &
     fig_persist_layout(B.persist + g.persistOff, g.capGg, g.nU, g.nP, g.rangeCap, g.nslots, sizeof(FigState), &P);
 }
 
-#ifndef FIG_WPE
-#define FIG_WPE 2          /* min waves per SIMD the kernels are register-allocated for (512-thread blocks: 2 => 1 block/CU.. ) */
-#endif
 // ---- sequential mode: whole gaps, one workgroup each (FIG_SCHED=seq)
 template <bool LDS_TAB, int NT>
 __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {

@@ -87,14 +87,6 @@ FIG_D double fig_wave_max_dpp(double v) {
 #endif
 }
 
-FIG_D double fig_wave_max(double v) {
-#ifdef FIG_EMU
-    return v;
-#else
-    for (int off = 32; off > 0; off >>= 1) { double y = __shfl_xor(v, off, 64); v = y > v ? y : v; }
-    return v;
-#endif
-}
 FIG_D unsigned long long fig_ballot(bool p) {
 #ifdef FIG_EMU
     return p ? 1ULL : 0ULL;
@@ -275,40 +267,6 @@ FIG_D void fig_hot_chain_e1(const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt
     } else fig_eblk1_compute_n(A, nlast, pa);
 }
 
-template <bool LDS>
-FIG_D void fig_hot_chain_m2(const double *C, int ncolE, fig_cu32p pk, int nw2, fig_cdp mt, int len, int xa, int xb, double &qa, double &qb) {
-    const int nblk = len >> 3;
-    for (int bi = 0; bi < nblk; bi++) {
-        const int j0 = bi * 8;
-        const uint32_t w = pk[bi >> 1] >> ((bi & 1) * 16);
-        fig_cdp k2 = mt + 2 * j0;
-        double kk[16];
-#pragma unroll
-        for (int q = 0; q < 16; q++) kk[q] = k2[q];
-        const double *ca = C + xa + j0, *cb = C + xb + j0;
-        double va[8], vb[8];
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) { int r = (int)((w >> (2 * jj)) & 3) * ncolE + jj; va[jj] = ca[r]; vb[jj] = cb[r]; }
-#pragma unroll
-        for (int jj = 0; jj < 8; jj++) {
-            const double fa = kk[2 * jj + 1] * va[jj], fb = kk[2 * jj + 1] * vb[jj];
-            qa *= (va[jj] < 0 ? kk[2 * jj] : fa);
-            qb *= (vb[jj] < 0 ? kk[2 * jj] : fb);
-        }
-    }
-    for (int j = nblk * 8; j < len; j++) {
-        const int b = (int)((pk[j >> 4] >> ((j & 15) * 2)) & 3);
-        const double m3 = mt[2 * j], e = mt[2 * j + 1];
-        const double va = C[b * ncolE + xa + j], vb = C[b * ncolE + xb + j];
-        const double fa = e * va, fb = e * vb;
-        qa *= (va < 0 ? m3 : fa);
-        qb *= (vb < 0 ? m3 : fb);
-    }
-}
-
-// MLE pair chain with exact pruning.  Every factor is <= 1, so a partial product only shrinks: once both partial
-// products of every lane of the wave are below `bound` (a product some placement of this read has already
-// ACHIEVED), none of them can be the arg-max and the rest of the round is skipped.  Returns false if pruned.
 struct FigMBlk { double kk[16]; double va[8], vb[8]; };
 
 template <bool LDS, int DX>
@@ -1088,7 +1046,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     if (rc == 2) {
                         if (va_ok && (qa > best.v || (qa == best.v && best.o != FIG_NOPOS && oa < best.o))) { best.v = qa; best.o = oa; }
                         if (vb_ok && (qb > best.v || (qb == best.v && best.o != FIG_NOPOS && ob < best.o))) { best.v = qb; best.o = ob; }
-                        double m = fig_wave_max(best.o == FIG_NOPOS ? init : best.v);
+                        double m = fig_wave_max_dpp(best.o == FIG_NOPOS ? init : best.v);
                         if (m > bound) bound = m;
                     } else if (rc == 1) {
                         const int base_a = obase + 2 * rr * stride;
