@@ -207,7 +207,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         K.persist_total = off;
     }
     struct ClsDef { int capGl, nt; };
-    const ClsDef defs[] = {{448, 256}, {1216, 512}, {1 << 30, 512}};
+    const ClsDef defs[] = {{448, 256}, {1216, 512}, {1600, 512}, {1 << 30, 512}};   // longest candidate (columns), threads
     K.order.clear(); K.classes.clear();
     const int L1 = m->max_read_length - 1;
     int prevcap = 0;
