@@ -613,6 +613,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         // reads per chunk; each wave stages its read's codes and its weight row, then all lanes add the chunk's rows
         // into the gap columns read by read (the reference's order), and lane 0 adds the per-read maxima in read order.
         unsigned char *const rb_keep = E.rb; double *const wbuf_keep = E.wbuf;
+        unsigned long long pfl = 0;                    // lane-local flop count of the partial passes
         // a partial read has at most len-1 <= 199 placements, so its weight row needs 208 doubles, not a full Wcap row:
         // every wave gets a row whenever the weight area (nteams x Wcap) holds nw such rows
         int nrow = E.nw < FIG_PLB_TEAMS ? E.nw : FIG_PLB_TEAMS;
@@ -657,7 +658,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                     t = fig_log(t);
                     if (t > best.v) { best.v = t; best.o = o; }
                     wr[o - w.lo] = fig_pow10(t);
-                    E.flops += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(o, len, G);
+                    pfl += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(o, len, G);
                 }
                 best = fig_wave_best(E, best);
                 if (E.lane == 0) { S.wv_v[E.wave] = best.v; S.wv_o[E.wave] = best.o; S.tm_lo[E.wave] = w.lo; S.tm_hi[E.wave] = w.hi; S.tm_len[E.wave] = len; }
@@ -722,7 +723,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                     for (; j < j1u; j++) { const int b = (int)((pkr[j >> 4] >> ((j & 15) * 2)) & 3); const double c = cc[b * ncolE_u + j]; const double f = mtf[2 * j + 1] * c; t *= (c < 0 ? mtf[2 * j] : f); }
                 }
                 if (t > best.v) { best.v = t; best.o = o; }
-                E.flops += (unsigned long long)(j1 - j0);
+                pfl += (unsigned long long)(j1 - j0);
             }
             best = fig_wave_best(E, best);
             if (E.lane == 0 && p < prc) {
@@ -736,6 +737,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             }
         }
         E.rb = rb_keep;
+        E.flops += pfl;
         FIG_SYNC();
         FIG_TICK(E, 5);
         if (E.tid == 0) {

@@ -467,6 +467,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
 #pragma unroll
     for (int m = 0; m < (CPL > 0 ? CPL : 1); m++) acc[m] = 0;
     const int pb_c = wave & 3, pb_x0 = (wave >> 2) * CPL * U.wsz + lane;       // this wave's base and first column
+    unsigned long long fl_acc = 0;                   // this lane's flops of the call: FigEng sits in private memory, one update per call
 #ifndef FIG_EMU
     uint32_t *plb = (uint32_t *)(fig_lds + fig_u(E.off_plb));
 #else
@@ -584,7 +585,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 wrow[o] = fig_exp(0.5 * t);
                 nplace++; nadd += fig_ovl(o, rs.len, G);
             }
-            E.flops += 4ULL * nplace * (unsigned long long)rs.len + nadd;
+            fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
             // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do
             { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
               if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? 0 : FIG_NOPOS; } }
@@ -698,6 +699,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             if (x < G) E.scr.cnt[pb_c * cg + x] = acc[i];
         }
     }
+    E.flops += fl_acc;
     FIG_SYNC();
 }
 
@@ -841,6 +843,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
+    unsigned long long fl_acc = 0;                   // lane-local flop count, added to E.flops once
     // per-wave factor buffer of fig_mle_serial: the weight rows are idle during the MLE pass
     double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
@@ -1074,7 +1077,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 if (q > best.v) { best.v = q; best.o = o; }
                 nplace++;
             }
-            E.flops += nplace * (unsigned long long)rs.len;
+            fl_acc += nplace * (unsigned long long)rs.len;
             best = fig_wave_best(E, best);
             // ---- the wave finishes its read (no workgroup barrier anywhere in this loop): accept test + integer pile-up
             FigBest b;
@@ -1126,6 +1129,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
         }
         FIG_TICK(E, 3);
     }
+    E.flops += fl_acc;
     FIG_SYNC();
     if (nci_lds) {
         for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = nl[j * nst + x];
