@@ -157,7 +157,7 @@ def main():
     alg_bytes = up["packed_bytes"] * args.steps + filled
     out["roofline"] = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_NOFMA_PEAK_TFLOPS,
                        "peak_note": "FP64 vector issue without FMA (256 CU x 4 SIMD x 16 lanes x 2.4 GHz): multiply and add must stay unfused for bit-exactness", "peak_with_fma": 2 * FP64_NOFMA_PEAK_TFLOPS, "frac_of_fma_peak": ach / (2 * FP64_NOFMA_PEAK_TFLOPS),
-                       "traffic": None, "kernel": "fig_eval_kernel<LDS_TAB,NT> (+ fig_begin/replay/end: all launches of one fill, 3 class lanes)", "launches_per_step": st["n_launches"], "kernel_ms_per_step": kernel_ms_avg / max(args.steps, 1),
+                       "traffic": None, "traffic_note": "not collectable inside this process; rocprofv3 --pmc passes of this command (profiles/round1): FETCH_SIZE x2 + WRITE_SIZE = 2.2e12 B per default step = 65 GB/s = 0.8 % of HBM peak, against 1.3e8 algorithmic bytes: per-workgroup scratch slabs, per-gap state slabs and register save frames of ~1800 resident workgroups cycling through L2, not input re-reads", "kernel": "fig_eval_kernel<LDS_TAB,NT> (+ fig_begin/replay/end: all launches of one fill, 3 class lanes)", "launches_per_step": st["n_launches"], "kernel_ms_per_step": kernel_ms_avg / max(args.steps, 1),
                        "alg_flops_per_step": flops_all / world / max(args.steps, 1), "placeReads_calls_per_step": place_calls / max(args.steps, 1),
                        "hbm": {"achieved": alg_bytes / max(ksec, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": alg_bytes / max(ksec, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg_bytes / max(args.steps, 1),
