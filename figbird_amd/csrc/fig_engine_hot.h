@@ -31,13 +31,26 @@ FIG_D FigBest fig_wave_best(const FigEng &E, FigBest x) {
     return x;
 #else
     (void)E;
-    for (int off = 32; off > 0; off >>= 1) {
-        FigBest y;
-        y.v = __shfl_down(x.v, off, 64);
-        y.o = __shfl_down(x.o, off, 64);
-        x = fig_best_merge(x, y);
-    }
-    return x;                         // valid in lane 0
+    // DPP row shifts / broadcasts (row_shr:1,2,4,8, row_bcast:15, row_bcast:31): lane 63 ends up with the merge of all
+    // lanes; lanes that receive nothing merge with an empty entry.  The merge is order-independent (larger v, then
+    // smaller o), so the scan order does not matter.
+#define FIG_DPP_BEST(ctrl, rmask) do { \
+        long long b_; memcpy(&b_, &x.v, 8); \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, (int)(b_ & 0xffffffffLL), ctrl, rmask, 0xf, false); \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, (int)(b_ >> 32), ctrl, rmask, 0xf, false); \
+        const int oo_ = __builtin_amdgcn_update_dpp(FIG_NOPOS, x.o, ctrl, rmask, 0xf, false); \
+        FigBest y_; long long o2_ = ((long long)hi_ << 32) | (unsigned int)lo_; memcpy(&y_.v, &o2_, 8); y_.o = oo_; \
+        x = fig_best_merge(x, y_); } while (0)
+    FIG_DPP_BEST(0x111, 0xf); FIG_DPP_BEST(0x112, 0xf); FIG_DPP_BEST(0x114, 0xf); FIG_DPP_BEST(0x118, 0xf);
+    FIG_DPP_BEST(0x142, 0xa); FIG_DPP_BEST(0x143, 0xc);
+#undef FIG_DPP_BEST
+    // callers read the result in lane 0
+    long long b2; memcpy(&b2, &x.v, 8);
+    const unsigned int l = (unsigned int)__builtin_amdgcn_readlane((int)(b2 & 0xffffffffLL), 63), h = (unsigned int)__builtin_amdgcn_readlane((int)(b2 >> 32), 63);
+    b2 = (long long)(((unsigned long long)h << 32) | l);
+    memcpy(&x.v, &b2, 8);
+    x.o = __builtin_amdgcn_readlane(x.o, 63);
+    return x;                         // valid in every lane
 #endif
 }
 
