@@ -6,23 +6,34 @@ BASELINE.json (SURVEY.md §8d recipe), with the FP64 roofline of the dominant ke
   (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 Workload: the jump-library (unmapped-mode) fill pass -- the expensive iteration of RunFigbird.sh's schedule --
-over a batch of gaps drawn from the synthetic set's distribution: scaffolds of 50 kb with a gap every 5 kb,
-GAGE-like gap-length mix, 2x150-bp reads with insert N(3500, 350), mean 10^3 reads per gap (10^8 reads /
-10^5 gaps, capped at 3000 as Preprocess does), 0.5 % substitutions.  A bit-exact fill of the whole 10^5-gap
-set is ~10^17 FP64 flops (hours on any hardware, CPU-years for the reference), so a "step" is one fill pass
-over a fixed per-GPU batch of `--gaps-per-gpu` gaps sampled (seeded) from that distribution, resident in HBM.
-Weak scaling: every rank gets its own batch of the same size; results are all-gathered (RCCL) every step.
-One JSON line on stdout (rank 0)."""
+over gaps drawn from the synthetic set's distribution: scaffolds of 50 kb with a gap every 5 kb, GAGE-like
+gap-length mix, 2x150-bp reads with insert N(3500, 350), mean 10^3 reads per gap (10^8 reads / 10^5 gaps, capped
+at 3000 as Preprocess does), 0.5 % substitutions.  A bit-exact fill of the whole 10^5-gap set is ~10^17 FP64
+flops (hours on any hardware, CPU-years for the reference), so a "step" is one fill pass over a fixed seeded
+sample of `--gaps-per-gpu` x N gaps of that distribution, resident in HBM (`full_set_seconds_est` extrapolates).
+
+Multi-GPU (weak scaling): every rank generates the same global sample (same seed), the product's partitioner
+(figbird_amd.dist.partition_lpt on estimate_cost: the role of FillGaps.cpp:456-649) deals it into N shards, each rank
+fills its shard through the C ABI, and one all-gather of packed byte buffers per step reassembles the results.
+
+Wall budget: the whole run (imports, generation, CPU baseline, partial pass, warm-up and timed steps) is kept
+inside `--budget-s` seconds.  The first fill is timed; warm-up and step counts are then clamped to what fits and
+the line reports the counts actually run (`steps`, `warmup`) beside `requested_steps` / `requested_warmup`.
+One JSON line on stdout (rank 0), also when the budget runs out or the process receives SIGTERM."""
 from __future__ import annotations
+
+import time
+
+T_PROC0 = time.perf_counter()
 
 import argparse
 import json
 import os
 import shutil
+import signal
 import subprocess
 import sys
 import tempfile
-import time
 
 import numpy as np
 
@@ -34,18 +45,43 @@ sys.path.insert(0, ROOT)
 # each instruction is ONE flop: peak = 39.3 TFLOP/s (the 78.6 TFLOP/s datasheet figure counts an FMA as two).
 FP64_NOFMA_PEAK_TFLOPS = 39.3
 HBM_PEAK_GBS = 8000.0
+FULL_SET_GAPS = 100000
+TRAFFIC_SIDECAR = os.path.join(ROOT, "profiles", "traffic_sidecar.json")
+
+OUT = {}                 # the JSON line, filled in as results arrive
+_EMITTED = False
 
 
 def log(*a):
     if int(os.environ.get("RANK", "0")) == 0:
-        print(*a, file=sys.stderr, flush=True)
+        print(f"[bench +{time.perf_counter() - T_PROC0:6.1f}s]", *a, file=sys.stderr, flush=True)
+
+
+def emit():
+    global _EMITTED
+    if _EMITTED or int(os.environ.get("RANK", "0")) != 0 or not OUT:
+        return
+    _EMITTED = True
+    print(json.dumps(OUT), flush=True)
+
+
+def _on_term(signum, frame):          # killed from outside: leave whatever has been measured so far
+    OUT.setdefault("note", f"terminated by signal {signum} before the run finished; fields present are final")
+    emit()
+    os._exit(0 if "value" in OUT else 1)
+
+
+def workload_key(args, world):
+    return f"{args.mode}|{args.mix}|g{args.gaps_per_gpu}|r{args.reads_per_gap:g}|s{args.seed}|n{world}"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1)
-    ap.add_argument("--warmup", type=int, default=0)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("FIGBENCH_BUDGET_S", "430")),
+                    help="wall budget of the whole run; warm-up/steps are clamped to fit")
     ap.add_argument("--gaps-per-gpu", type=int, default=512)
     ap.add_argument("--reads-per-gap", type=float, default=1000.0)
     ap.add_argument("--mix", default="gage", choices=["gage", "loguniform"])
@@ -55,9 +91,10 @@ def main():
     ap.add_argument("--partial-pass", type=int, default=1, help="also report the partial-mode pass (untimed extra)")
     ap.add_argument("--cpu-sample-gaps", type=int, default=0, help="0 = five gaps per host core from the >400-bp bracket")
     args = ap.parse_args()
+    signal.signal(signal.SIGTERM, _on_term)
 
     import torch
-    from figbird_amd import api, synth, dist as fdist, build as fbuild
+    from figbird_amd import api, synth, dist as fdist
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -71,6 +108,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+    log(f"imports + init done (budget {args.budget_s:.0f} s)")
+
+    def left():
+        return args.budget_s - (time.perf_counter() - T_PROC0)
 
     if args.mode == "unmapped":
         spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=args.reads_per_gap, gap_mix=args.mix)
@@ -85,12 +126,17 @@ def main():
                                  unmapped_flag=int(spec.mode == "unmapped"), script_itr=1, max_distance=spec.max_distance,
                                  read_length=spec.read_len, neg_overlap=30, partial_len=mc.partial_len)
 
-    # ---- this rank's batch (weak scaling: same size and distribution on every rank, different seed)
-    t0 = time.time()
-    batch, truth = synth.make_bench_batch(args.seed + 1000 * rank, args.gaps_per_gpu, spec)
+    # ---- the global sample (identical on every rank) and this rank's shard of it
+    gbatch, truth = synth.make_bench_batch(args.seed, args.gaps_per_gpu * world, spec)
+    n_global = gbatch.n_gaps
+    off = gbatch.u_read_off if spec.mode == "unmapped" else gbatch.p_read_off
+    cost = fdist.estimate_cost(np.asarray(gbatch.gap_len), np.diff(off), spec.read_len, spec.mode == "unmapped", mc.partial_len)
+    shards = fdist.partition_lpt(cost, world)
+    my_ids = shards[rank]
+    batch = gbatch if world == 1 else synth.subset_batch(gbatch, my_ids)
     n_gaps = batch.n_gaps
     n_reads = int(batch.u_read_off[-1]) if spec.mode == "unmapped" else int(batch.p_read_off[-1])
-    log(f"[bench] rank {rank}: {n_gaps} gaps, {n_reads} reads generated in {time.time() - t0:.1f}s")
+    log(f"rank {rank}: shard of {n_gaps}/{n_global} gaps, {n_reads} reads")
 
     eng = api.Engine(local)
     eng.set_model(model)
@@ -99,10 +145,9 @@ def main():
 
     def one_step():
         res = eng.fill_resident()
-        ids = list(range(rank * n_gaps, (rank + 1) * n_gaps))
         if world > 1:
-            fl, gt, ss = fdist.all_gather_results(ids, res.filled_len, res.gaptofill, res.strings, world * n_gaps, device=dev)
-            filled = sum(len(s) - s.count("N") for s in ss)
+            fl, gt, ss = fdist.all_gather_packed(my_ids, res, n_global, device=dev)
+            filled = ss.filled_bases()
         else:
             filled = res.filled_bases
         return res, filled, eng.stats()
@@ -113,78 +158,154 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def allmax(x):
+        if world == 1:
+            return float(x)
+        import torch.distributed as dist
+        t = torch.tensor([x], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    OUT.update({
+        "metric": "gaps/sec (+ filled-bases/sec), synthetic 1e5-gap set recipe, jump-library fill pass",
+        "unit": "gaps/s", "n_gaps": n_global, "n_gpus": world, "requested_steps": args.steps, "requested_warmup": args.warmup,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, seeded sample of {args.gaps_per_gpu} gaps/GPU from the {args.mix} gap mix",
+                   "gaps_per_gpu": args.gaps_per_gpu, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
+                   "insert": [spec.insert_mean, spec.insert_sd], "substitution_rate": spec.err,
+                   "sharding": f"{n_global} gaps dealt LPT on estimated cost over {world} rank(s), no data-path collective, 1 all-gather of packed results per step"},
+    })
+
+    # ---- first fill: timed on its own, counts as warm-up; everything after it is clamped to the budget
+    barrier()
+    t0 = time.perf_counter()
+    res, filled, st = one_step()
+    barrier()
+    t_first = allmax(time.perf_counter() - t0)
+    warm_done = 1
+    log(f"first fill {t_first:.1f} s ({st['kernel_ms'] / 1e3:.1f} s of kernels), {left():.0f} s of budget left")
+
+    # ---- CPU baseline + the other mode's pass (rank 0, N=1 only), before the timed loop and inside the budget
+    extras_s = 0.0
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        if left() > 2.5 * t_first + 75:
+            t = time.perf_counter()
+            try:
+                OUT["cpu_baseline"] = cpu_baseline(args, spec, batch, mc, res, eng, work, st, left() - 2.5 * t_first - 20)
+            except Exception as e:  # pragma: no cover
+                OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+            extras_s += time.perf_counter() - t
+            log(f"cpu_baseline done in {time.perf_counter() - t:.1f} s")
+        else:
+            OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "reference", "sample": "skipped: wall budget too short"}
+    if rank == 0 and world == 1 and args.mode == "unmapped" and args.partial_pass and left() > 2.5 * t_first + 30:
+        t = time.perf_counter()
+        try:
+            OUT["partial_pass"] = partial_pass(args, local, work)
+        except Exception as e:  # pragma: no cover
+            OUT["partial_pass"] = {"value": None, "unit": "gaps/s", "note": f"failed: {e!r}"}
+        extras_s += time.perf_counter() - t
+
+    # ---- clamp warm-up and steps to what is left (10 s reserve for teardown); timed steps come first
+    left_min = -allmax(-left())                       # the rank with the least budget left decides
+    fit = int(max(0.0, left_min - 10.0) / max(t_first, 1e-3))
+    steps = max(1, min(args.steps, fit))
+    warm_more = max(0, min(args.warmup - warm_done, fit - steps))
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([steps, warm_more], dtype=torch.int64, device=dev)
+        dist.broadcast(t, src=0)
+        steps, warm_more = int(t[0]), int(t[1])
+    log(f"running {warm_more} more warm-up + {steps} timed steps (requested {args.warmup}/{args.steps})")
+    for _ in range(warm_more):
         one_step()
     barrier()
     t0 = time.perf_counter()
     kernel_ms = 0.0
     flops = 0.0
     place_calls = 0
-    filled = 0
-    res = None
-    for _ in range(args.steps):
+    for i in range(steps):
         res, filled, st = one_step()
         kernel_ms += st["kernel_ms"]; flops += st["alg_flops"]; place_calls += st["place_calls"]
+        log(f"step {i + 1}/{steps}: kernels {st['kernel_ms'] / 1e3:.2f} s")
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed = allmax(time.perf_counter() - t0)
+    per_rank_kernel_ms = [kernel_ms / steps]
     if world > 1:
         import torch.distributed as dist
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
         agg = torch.tensor([kernel_ms, flops, float(place_calls)], dtype=torch.float64, device=dev)
-        dist.all_reduce(agg, op=dist.ReduceOp.SUM)
-        kernel_ms_sum, flops_all = float(agg[0]), float(agg[1])
-        kernel_ms_avg = kernel_ms_sum / world
+        every = [torch.zeros_like(agg) for _ in range(world)]
+        dist.all_gather(every, agg)
+        per_rank_kernel_ms = [float(e[0]) / steps for e in every]
+        flops_all = float(sum(float(e[1]) for e in every))
+        place_all = float(sum(float(e[2]) for e in every))
+        kernel_ms_max = max(float(e[0]) for e in every)
     else:
-        kernel_ms_avg, flops_all = kernel_ms, flops
+        flops_all, place_all, kernel_ms_max = flops, float(place_calls), kernel_ms
 
-    total_gaps = world * n_gaps * args.steps
+    total_gaps = n_global * steps
     gaps_per_s = total_gaps / elapsed
-    out = {
-        "metric": "gaps/sec (+ filled-bases/sec), synthetic 1e5-gap set recipe, jump-library fill pass",
-        "value": gaps_per_s, "unit": "gaps/s", "n_gaps": world * n_gaps, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / max(args.steps, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64", "data": "synthetic",
-        "filled_bases_per_s": filled * args.steps / elapsed,
-        "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, batch of {n_gaps} gaps/GPU sampled from the {args.mix} gap mix",
-                   "gaps_per_gpu": n_gaps, "reads_per_gap_mean": n_reads / max(n_gaps, 1), "read_len": spec.read_len,
-                   "insert": [spec.insert_mean, spec.insert_sd], "substitution_rate": spec.err, "sharding": f"gaps x{world} ranks, 1 all-gather/step"},
-    }
-    # ---- roofline of the dominant kernel (fig_fill_kernel): algorithmic FP64 flops / HIP-event kernel time
-    ksec = kernel_ms_avg / 1e3
-    ach = flops_all / world / max(ksec, 1e-12) / 1e12 if world > 1 else flops_all / max(ksec, 1e-12) / 1e12
-    alg_bytes = up["packed_bytes"] * args.steps + filled
-    out["roofline"] = {"bound": "fp64_valu", "achieved": ach, "peak": FP64_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_NOFMA_PEAK_TFLOPS,
-                       "peak_note": "FP64 vector issue without FMA (256 CU x 4 SIMD x 16 lanes x 2.4 GHz): multiply and add must stay unfused for bit-exactness", "peak_with_fma": 2 * FP64_NOFMA_PEAK_TFLOPS, "frac_of_fma_peak": ach / (2 * FP64_NOFMA_PEAK_TFLOPS),
-                       "traffic": None, "traffic_note": "not collectable inside this process; rocprofv3 --pmc passes of this command (profiles/round1): FETCH_SIZE x2 + WRITE_SIZE = 2.2e12 B per default step = 65 GB/s = 0.8 % of HBM peak, against 1.3e8 algorithmic bytes: per-workgroup scratch slabs, per-gap state slabs and register save frames of ~1800 resident workgroups cycling through L2, not input re-reads", "kernel": "fig_eval_kernel<LDS_TAB,NT> (+ fig_begin/replay/end: all launches of one fill, 3 class lanes)", "launches_per_step": st["n_launches"], "kernel_ms_per_step": kernel_ms_avg / max(args.steps, 1),
-                       "alg_flops_per_step": flops_all / world / max(args.steps, 1), "placeReads_calls_per_step": place_calls / max(args.steps, 1),
-                       "hbm": {"achieved": alg_bytes / max(ksec, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                               "frac": alg_bytes / max(ksec, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg_bytes / max(args.steps, 1),
-                               "note": "path is FP64-ALU bound (~1e5-1e7 flop/byte); HBM figure reported because the north star asks for it"}}
-
-    # ---- CPU baseline: rank 0, N=1 only; bounded sample (the >400-bp bracket: one candidate length, a few EM
-    # iterations, ~1-2 s per gap per core, five per core; a <=400-bp gap of this set costs 10^2-10^3 CPU-seconds)
-    if rank == 0 and world == 1 and args.cpu_baseline:
-        try:
-            out["cpu_baseline"] = cpu_baseline(args, spec, batch, mc, res, eng, work)
-        except Exception as e:  # pragma: no cover
-            out["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+    OUT.update({"value": gaps_per_s, "steps": steps, "warmup": warm_done + warm_more, "ms_per_step": 1e3 * elapsed / steps,
+                "filled_bases_per_s": filled * steps / elapsed,
+                "full_set_seconds_est": FULL_SET_GAPS / gaps_per_s,
+                "full_set_note": f"{FULL_SET_GAPS} gaps of this mix at the measured rate; the timed step is a {n_global}-gap seeded sample of that set",
+                "first_fill_s": t_first, "wall_s_before_timed_loop": t0 - T_PROC0})
+    # ---- roofline of the dominant kernel (fig_eval_kernel): algorithmic FP64 flops / HIP-event kernel time.  For N > 1
+    # the chip-level figure is per GPU: this rank set's flops / N over the slowest rank's kernel time.
+    ksec = kernel_ms_max / 1e3
+    ach = flops_all / world / max(ksec, 1e-12) / 1e12
+    alg_bytes = up["packed_bytes"] * steps + filled * steps / max(world, 1)
+    traffic, traffic_note = read_traffic(args, world)
+    OUT["roofline"] = {
+        "bound": "fp64_valu", "achieved": ach, "peak": FP64_NOFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / FP64_NOFMA_PEAK_TFLOPS,
+        "peak_note": "FP64 vector issue without FMA (256 CU x 4 SIMD x 16 lanes x 2.4 GHz): multiply and add must stay unfused for bit-exactness",
+        "peak_with_fma": 2 * FP64_NOFMA_PEAK_TFLOPS, "frac_of_fma_peak": ach / (2 * FP64_NOFMA_PEAK_TFLOPS),
+        "executed_note": "achieved counts the SURVEY §8d formula (4L E-step + 1L MLE + pile-up adds per placement); the MLE term is pruned exactly on the device, see executed_frac",
+        "traffic": traffic, "traffic_note": traffic_note,
+        "kernel": "fig_eval_kernel<LDS_TAB,NT> (+ fig_begin/replay/end: all launches of one fill, concurrent class lanes)",
+        "launches_per_step": st["n_launches"], "kernel_ms_per_step": kernel_ms_max / steps, "per_rank_kernel_ms_per_step": per_rank_kernel_ms,
+        "alg_flops_per_step": flops_all / world / steps, "placeReads_calls_per_step": place_all / steps,
+        "hbm": {"achieved": alg_bytes / max(ksec, 1e-12) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": alg_bytes / max(ksec, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg_bytes / steps,
+                "note": "path is FP64-ALU bound (~1e5-1e7 flop/byte); HBM figure reported because the north star asks for it"}}
+    if st.get("spec_flops", 0) > 0 and st.get("mle_alg_flops", 0) > 0:
+        # credited flops the device really executed: everything but the pruned part of the MLE term (ratios taken over all
+        # evaluations of the last step, discarded speculation included)
+        mle_share = st["mle_alg_flops"] / st["spec_flops"]
+        mle_done = min(1.0, st["mle_exec_flops"] / st["mle_alg_flops"])
+        OUT["roofline"]["mle_share_of_alg_flops"] = mle_share
+        OUT["roofline"]["mle_fraction_executed"] = mle_done
+        OUT["roofline"]["executed_frac"] = OUT["roofline"]["frac"] * (1.0 - mle_share * (1.0 - mle_done))
+        OUT["roofline"]["discarded_speculation_frac"] = max(0.0, 1.0 - st["alg_flops"] / st["spec_flops"])
+    if "cpu_baseline" in OUT and OUT["cpu_baseline"].get("gflops"):
+        cb = OUT["cpu_baseline"]
+        # same-mix figure: the reference does the same algorithmic flops per gap (control flow is bit-identical), so the
+        # mix costs it alg_flops_per_step / its measured flop rate
+        mix_s = (flops_all / steps) / (cb["gflops"] * 1e9)
+        cb["value"] = n_global / mix_s
+        cb["value_note"] = ("same-mix extrapolation: this step's algorithmic flops / the reference's measured flop rate on the sample "
+                            f"= {mix_s:.0f} s per step on {cb['cores']} cores; measured_sample_gaps_per_s is the raw sample figure (cheapest bracket only)")
     eng.free_batch()
     eng.close()
-    # ---- the other mode of the reference's schedule (frag-library partial-mode pass over a batch of the same gap mix),
-    # outside the timed region, reported beside the headline: rank 0, N=1 only
-    if rank == 0 and world == 1 and args.mode == "unmapped" and args.partial_pass:
-        try:
-            out["partial_pass"] = partial_pass(args, local, work)
-        except Exception as e:  # pragma: no cover
-            out["partial_pass"] = {"value": None, "unit": "gaps/s", "note": f"failed: {e!r}"}
     shutil.rmtree(work, ignore_errors=True)
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    OUT["wall_s_total"] = time.perf_counter() - T_PROC0
+    emit()
+
+
+def read_traffic(args, world):
+    """HBM bytes per step from the PMC passes of this same command (tools/profile_bench.sh writes the sidecar from
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters cannot be read from inside the process)."""
+    try:
+        sc = json.load(open(TRAFFIC_SIDECAR))
+        ent = sc.get(workload_key(args, world))
+        if ent:
+            return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
+        return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"
+    except Exception as e:
+        return None, f"profiles/traffic_sidecar.json unreadable: {e!r}"
 
 
 def partial_pass(args, local, work):
@@ -198,6 +319,7 @@ def partial_pass(args, local, work):
     eng = api.Engine(local)
     eng.set_model(model)
     eng.upload(batch)
+    eng.fill_resident()                     # warm-up
     res = eng.fill_resident()
     st = eng.stats()
     eng.free_batch(); eng.close()
@@ -208,28 +330,13 @@ def partial_pass(args, local, work):
             "workload": "frag-library (2x101 bp, insert 180) partial-mode pass, same gap mix, kernel time of one fill"}
 
 
-def cpu_baseline(args, spec, batch, mc, res, eng, work):
-    from figbird_amd import synth, build as fbuild
-    cores = min(os.cpu_count() or 1, 16)
-    k = args.cpu_sample_gaps or cores * 5
-    G = np.asarray(batch.gap_len)
-    if spec.mode == "unmapped":
-        nread = np.diff(batch.u_read_off)
-        cand = [int(g) for g in np.argsort(nread) if G[g] > 400]
-        label = ">400-bp bracket"
-    else:
-        cand = [int(g) for g in range(batch.n_gaps)]
-        label = "all brackets"
-    sample = cand[:k] if spec.mode == "unmapped" else cand[:max(k * 64, 256)]
-    if not sample:
-        raise RuntimeError("no gap fits the CPU sample")
-    root = os.path.join(work, "cpu")
+def _run_ref_sample(exe, kind, sample, batch, mc, spec, root, cores, timeout_s):
+    """Fill `sample` (gap ids of `batch`) with one CPU process per core; returns (wall, shards, paths, order) or None on timeout."""
+    from figbird_amd import synth
     paths = synth.write_batch_subset(batch, sample, mc, root, spec)
     order = paths["gap_order"]
-    sel = [i for i, g in enumerate(order) if g in set(sample)]
-    ref = os.path.join(fbuild.REFDIR, "Figbird.out")
-    kind = "reference" if os.path.exists(ref) else "port"
-    exe = [ref] if kind == "reference" else [fbuild.ORACLE, "figbird"]
+    sset = set(sample)
+    sel = [i for i, g in enumerate(order) if g in sset]
     nproc = min(cores, len(sel))
     shards = [sel[i::nproc] for i in range(nproc)]
     with open(paths["tmp"] + "gaploads.txt", "w") as f:
@@ -242,9 +349,45 @@ def cpu_baseline(args, spec, batch, mc, res, eng, work):
         cmd = exe + [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", str(int(spec.mode == "partial")), str(int(spec.mode == "unmapped")),
                      str(t), str(len(sh))] + argv_tail
         procs.append(subprocess.Popen(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=root))
+    ok = True
     for p in procs:
-        p.wait()
+        try:
+            p.wait(timeout=max(1.0, timeout_s - (time.perf_counter() - t0)))
+        except subprocess.TimeoutExpired:
+            ok = False
+            p.kill(); p.wait()
     wall = time.perf_counter() - t0
+    return (wall, shards, paths, order) if ok else None
+
+
+def cpu_baseline(args, spec, batch, mc, res, eng, work, st_full, budget_s):
+    """The reference (oracle/_ref/Figbird.out, -O2 and as-shipped -O0) or the oracle port on the host cores, on a bounded
+    sample of the SAME batch.  A <=400-bp gap of this set costs the reference 10^2-10^3 CPU-seconds, so the sample is
+    the >400-bp bracket (one candidate length, a few EM iterations: ~1-2 s per gap per core); the same-mix figure in
+    `value` is derived in main() from the reference's measured flop rate and the step's algorithmic flops."""
+    from figbird_amd import synth
+    from tools import build_test_infra as fbuild    # checker binaries only (oracle / oracle/_ref): the CPU baseline leg
+    cores = min(os.cpu_count() or 1, 16)
+    k = args.cpu_sample_gaps or cores * 5
+    G = np.asarray(batch.gap_len)
+    if spec.mode == "unmapped":
+        nread = np.diff(batch.u_read_off)
+        cand = [int(g) for g in np.argsort(nread, kind="stable") if G[g] > 400]
+        label = ">400-bp bracket"
+        sample = cand[:k]
+    else:
+        label = "all brackets"
+        sample = list(range(batch.n_gaps))[:max(k * 64, 256)]
+    if not sample:
+        raise RuntimeError("no gap fits the CPU sample")
+    ref = os.path.join(fbuild.REFDIR, "Figbird.out")
+    ref0 = os.path.join(fbuild.REFDIR, "Figbird_O0.out")
+    kind = "reference" if os.path.exists(ref) else "port"
+    exe = [ref] if kind == "reference" else [fbuild.ORACLE, "figbird"]
+    r = _run_ref_sample(exe, kind, sample, batch, mc, spec, os.path.join(work, "cpu"), cores, min(budget_s * 0.6, 90.0))
+    if r is None:
+        raise RuntimeError("CPU sample did not finish inside its budget")
+    wall, shards, paths, order = r
     # parity spot-check of the sample against the GPU results + its algorithmic flops (GPU counters on the same gaps)
     ok = True
     for t, sh in enumerate(shards):
@@ -260,13 +403,26 @@ def cpu_baseline(args, spec, batch, mc, res, eng, work):
     st = eng.stats()
     eng.free_batch()
     eng.upload(batch)
-    return {"value": len(sample) / wall, "unit": "gaps/s", "cores": nproc, "kind": kind,
-            "sample": f"{len(sample)} gaps of the batch from the {label} ({int(G[sample].min())}-{int(G[sample].max())} bp, "
-                      f"{int(np.diff(batch.u_read_off)[sample].mean()) if spec.mode == 'unmapped' else int(np.diff(batch.p_read_off)[sample].mean())} reads/gap), "
-                      f"one {'oracle/_ref/Figbird.out (-O2 build of the reference)' if kind == 'reference' else 'oracle port'} process per core, {wall:.1f} s wall",
-            "gflops": st["alg_flops"] / wall / 1e9, "gpu_same_sample_gaps_per_s": len(sample) / max(st["kernel_ms"] / 1e3, 1e-9),
-            "gpu_same_sample_gflops": st["alg_flops"] / max(st["kernel_ms"] / 1e3, 1e-9) / 1e9, "parity_on_sample": bool(ok)}
+    nmean = int(np.diff(batch.u_read_off)[sample].mean()) if spec.mode == "unmapped" else int(np.diff(batch.p_read_off)[sample].mean())
+    out = {"value": len(sample) / wall, "unit": "gaps/s", "cores": len(shards), "kind": kind,
+           "sample": f"{len(sample)} gaps of the batch from the {label} ({int(G[sample].min())}-{int(G[sample].max())} bp, {nmean} reads/gap), "
+                     f"one {'oracle/_ref/Figbird.out (-O2 build of the reference)' if kind == 'reference' else 'oracle port'} process per core, {wall:.1f} s wall",
+           "measured_sample_gaps_per_s": len(sample) / wall,
+           "gflops": st["alg_flops"] / wall / 1e9, "gpu_same_sample_gaps_per_s": len(sample) / max(st["kernel_ms"] / 1e3, 1e-9),
+           "gpu_same_sample_gflops": st["alg_flops"] / max(st["kernel_ms"] / 1e3, 1e-9) / 1e9, "parity_on_sample": bool(ok)}
+    # as-shipped build (RunFigbird.sh never passes -O): one gap per core from the same sample
+    if kind == "reference" and os.path.exists(ref0) and budget_s - wall > 40:
+        s0 = sample[:cores]
+        r0 = _run_ref_sample([ref0], kind, s0, batch, mc, spec, os.path.join(work, "cpu_O0"), cores, min(45.0, budget_s - wall - 10))
+        if r0 is not None:
+            frac = sum(1 for _ in s0) / len(sample)
+            out["as_shipped_O0"] = {"gaps_per_s": len(s0) / r0[0], "wall_s": r0[0], "sample": f"first {len(s0)} gaps of the same sample, oracle/_ref/Figbird_O0.out (g++ without -O, as RunFigbird.sh builds it)",
+                                    "slowdown_vs_O2_est": (r0[0] / len(s0)) / (wall / len(sample)) if frac else None}
+    return out
 
 
 if __name__ == "__main__":
-    main()
+    try:
+        main()
+    finally:
+        emit()

@@ -58,7 +58,8 @@ class FigGapResults(C.Structure):
 class FigStats(C.Structure):
     _fields_ = [("kernel_ms", C.c_double), ("h2d_ms", C.c_double), ("d2h_ms", C.c_double),
                 ("packed_bytes", C.c_int64), ("place_calls", C.c_int64), ("alg_flops", C.c_double),
-                ("n_launches", C.c_int32)]
+                ("n_launches", C.c_int32), ("pad0", C.c_int32), ("spec_flops", C.c_double),
+                ("mle_alg_flops", C.c_double), ("mle_exec_flops", C.c_double)]
 
 
 EXPORTS = ["fig_version", "fig_strerror", "fig_ctx_create", "fig_ctx_destroy", "fig_ctx_set_model",
@@ -240,6 +241,8 @@ class FillResult:
     strings: List[str]
     cand: Optional[list] = None     # per gap: list of (gapEstimate, iterations, valid_count, likelihood)
     n_place: Optional[np.ndarray] = None
+    str_off: Optional[np.ndarray] = None   # int64[n+1]: gap g's string is raw[str_off[g]:str_off[g+1]]
+    raw: Optional[np.ndarray] = None       # uint8: all gap strings back to back, as the C ABI wrote them
 
     @property
     def filled_bases(self) -> int:
@@ -302,7 +305,7 @@ class Engine:
                 k = min(int(dn[g]), debug_cand)
                 base = g * debug_cand
                 cand.append([(int(di[(base + j) * 3]), int(di[(base + j) * 3 + 1]), int(di[(base + j) * 3 + 2]), float(dl[base + j])) for j in range(k)])
-        res = FillResult(fl[:n].copy(), gt[:n].copy(), strings, cand)
+        res = FillResult(fl[:n].copy(), gt[:n].copy(), strings, cand, str_off=so, raw=st)
         res.n_place = dp[:n].copy() if debug_cand > 0 else None
         return res
 

@@ -1,7 +1,6 @@
-"""Build every native artefact in-tree (no JIT cache): libfighip.so (gfx950 HIP engine + C ABI),
-figfill (C++ host drop-in for FillGaps.cpp), and -- test infrastructure only -- the oracle
-restatement, the reference binaries (when /root/reference is present) and the one-lane
-emulation build of figfill used by the CPU unit tests."""
+"""Build the product's native artefacts in-tree (no JIT cache): libfighip.so (gfx950 HIP engine + C ABI),
+figfill (C++ host drop-in for FillGaps.cpp) and libfighost.so (the host code as a library for the Python
+binding).  Test infrastructure (oracle, oracle/_ref, the emulation build) is built by tools/build_test_infra.py."""
 from __future__ import annotations
 
 import os
@@ -17,10 +16,6 @@ BINDIR = os.path.join(PKG, "bin")
 LIB = os.path.join(LIBDIR, "libfighip.so")
 FIGFILL = os.path.join(BINDIR, "figfill")
 HOSTLIB = os.path.join(LIBDIR, "libfighost.so")
-EMU = os.path.join(ROOT, "tests", "emu", "figfill_emu")
-EMULIB = os.path.join(ROOT, "tests", "emu", "libfigemu.so")   # test-only: C ABI backed by the one-lane emulation
-ORACLE = os.path.join(ROOT, "oracle", "figbird_oracle")
-REFDIR = os.path.join(ROOT, "oracle", "_ref")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
 # -ffp-contract=off: the reference multiplies and adds separately (no FMA on its x86-64 build);
@@ -58,41 +53,32 @@ def build_lib(force: bool = False) -> str:
     return LIB
 
 
+def _host_sources():
+    host = os.path.join(CSRC, "host")
+    hdrs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h"))
+    libs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".cpp") and f.startswith("fig_"))
+    return host, hdrs, libs
+
+
 def build_figfill(force: bool = False) -> str:
+    """figfill (the FillGaps.cpp drop-in) and libfighost.so: every host/fig_*.cpp + figfill_main.cpp."""
     os.makedirs(BINDIR, exist_ok=True)
-    host = os.path.join(CSRC, "host")
-    srcs = [os.path.join(host, f) for f in ("figfill_main.cpp", "fig_host.cpp", "fig_host.h")]
+    host, hdrs, libs = _host_sources()
+    main_cpp = os.path.join(host, "figfill_main.cpp")
+    srcs = hdrs + libs + [main_cpp, os.path.join(ROOT, "include", "figbird_hip.h")]
+    common = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread"]
     if force or not _newer(FIGFILL, srcs + [LIB]):
-        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", FIGFILL,
-              os.path.join(host, "figfill_main.cpp"), os.path.join(host, "fig_host.cpp"),
-              "-L" + LIBDIR, "-lfighip", "-Wl,-rpath,$ORIGIN/../lib"])
+        _run(common + ["-o", FIGFILL, main_cpp] + libs + ["-L" + LIBDIR, "-lfighip", "-Wl,-rpath,$ORIGIN/../lib"])
     if force or not _newer(HOSTLIB, srcs):
-        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", HOSTLIB, os.path.join(host, "fig_host.cpp")])
+        _run(common + ["-fPIC", "-shared", "-o", HOSTLIB] + libs)
     return FIGFILL
-
-
-def build_test_infra(force: bool = False) -> None:
-    """oracle/ restatement, oracle/_ref (only where /root/reference exists) and the emu figfill."""
-    _run(["make", "-C", os.path.join(ROOT, "oracle"), "oracle"])
-    if os.path.exists("/root/reference/Figbird.cpp"):
-        need = force or not all(os.path.exists(os.path.join(REFDIR, f)) for f in ("Figbird.out", "Figbird_O0.out", "FillGaps.out"))
-        if need:
-            _run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"])
-    host = os.path.join(CSRC, "host")
-    srcs = [os.path.join(host, "figfill_main.cpp"), os.path.join(host, "fig_host.cpp"), os.path.join(host, "fig_host.h"),
-            os.path.join(ROOT, "tests", "emu", "fig_emu_abi.cpp")] + _csrc_files()
-    if force or not _newer(EMU, srcs):
-        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-o", EMU, srcs[0], srcs[1], srcs[3]])
-    if force or not _newer(EMULIB, srcs):
-        _run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared", "-o", EMULIB, srcs[3]])
 
 
 def build_all(force: bool = False) -> None:
     build_lib(force)
     build_figfill(force)
-    build_test_infra(force)
 
 
 if __name__ == "__main__":
     build_all("--force" in sys.argv)
-    print("built:", LIB, FIGFILL, ORACLE, EMU)
+    print("built:", LIB, FIGFILL, HOSTLIB)

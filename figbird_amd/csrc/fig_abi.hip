@@ -31,13 +31,15 @@
 #define FIG_PROF_BEGIN() ((void)0)
 #define FIG_PROF_FLUSH() ((void)0)
 #endif
+// MLE-pass accounting (raw totals incl. discarded speculation; only their ratio is reported): [3] credited, [4] executed
+#define FIG_FLUSH_MLE() do { if (E.mle_alg) atomicAdd(&B.counters[3], E.mle_alg); if (E.lane == 0 && E.mle_exec) atomicAdd(&B.counters[4], E.mle_exec); } while (0)
 struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel; };
 
 FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
     E.tid = threadIdx.x; E.nt = blockDim.x;
     E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
-    E.capG = A.capG; E.flops = 0; E.wait_cycles = 0;
+    E.capG = A.capG; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0;
     for (int i = 0; i < 22; i++) E.prof[i] = 0;
     E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
@@ -85,6 +87,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_fill_kernel(FigDe
     }
     FIG_PROF_FLUSH();
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
+    FIG_FLUSH_MLE();
 }
 
 // ---- candidate-parallel mode, kernel 1: setup + analyzeGap + checkGapReads per gap; skipped gaps finish here
@@ -115,6 +118,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_begin_kernel(FigD
         __syncthreads();
     }
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
+    FIG_FLUSH_MLE();
 }
 
 // ---- kernel 2: speculative candidate evaluations; items = {gap, candidate index j, slot, -}
@@ -138,6 +142,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_eval_kernel(FigDe
     }
     FIG_PROF_FLUSH();
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
+    FIG_FLUSH_MLE();
 }
 
 // ---- kernel 3: replay the bookkeeping of the speculated candidates in order; entries = {gap, n slots, -, -}
@@ -146,7 +151,7 @@ __global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBat
     FigEng E; FigScr work;
     memset(&work, 0, sizeof(work));
     E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
-    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
+    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
     E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.plb = nullptr; E.off_plb = 0; E.pq_lds = 0; E.w_lds = 0;
     E.off_pq = E.off_q4 = E.off_w = 0;
     E.S = (FigState *)fig_lds;
@@ -179,6 +184,7 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_end_kernel(FigDev
         __syncthreads();
     }
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
+    FIG_FLUSH_MLE();
 }
 
 // ------------------------------------------------------------------------------------- context
@@ -314,6 +320,7 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     if (m->partial_flag && m->unmapped_flag) return FIG_EUNSUP;      // the driver never sets both (RunFigbird.sh:211-216)
     if (m->insert_threshold_min < 0 || m->insert_threshold_max >= m->max_insert_size + 1) return FIG_EINVAL;
     hipSetDevice(ctx->device);
+    free_batch(ctx);                  // a resident batch was packed (classes, capacities, candidate ranges) under the previous model
     int L = m->max_read_length;
     ctx->hm = *m;
     ctx->h_e.assign(m->error_pos_dist, m->error_pos_dist + L);
@@ -429,10 +436,9 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     {   size_t blk = 0;
         for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
             const fig_ctx::Cls &c = ctx->classes[ci];
-            FigLane ln;
-            if (hipStreamCreate(&ln.stream) != hipSuccess || hipEventCreateWithFlags(&ln.done, hipEventDisableTiming) != hipSuccess) return FIG_EHIP;
-            ctx->lanes.push_back(ln);
+            ctx->lanes.push_back(FigLane());          // pushed first: free_batch reclaims whatever was created when a later step fails
             FigLane &l = ctx->lanes.back();
+            if (hipStreamCreate(&l.stream) != hipSuccess || hipEventCreateWithFlags(&l.done, hipEventDisableTiming) != hipSuccess) return FIG_EHIP;
             l.queue_head = db.queue_head + 16 * (ci + 1);
             l.scratch = db.scratch + (size_t)stride * blk; blk += (size_t)c.capacity;
             l.cap = (size_t)std::max(c.c.q_end - c.c.q_begin, 1) * 4 * (size_t)(K.nslots + 1);
@@ -611,6 +617,11 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         hipMemsetAsync(db.draw_isz, 0, (size_t)nr * 4, ctx->stream);
     }
     hipMemsetAsync(db.counters, 0, 256, ctx->stream);
+    // a previous call that failed half-way may have left queue heads / ping-pong selectors inconsistent: start clean
+    hipMemsetAsync(db.queue_head, 0, 64 * (ctx->classes.size() + 1), ctx->stream);
+    for (auto &l : ctx->lanes) l.qsel = 0;
+    hipMemsetAsync(db.filled_len, 0, (size_t)std::max<int64_t>(ng, 1) * 4, ctx->stream);
+    hipMemsetAsync(db.gaptofill, 0, (size_t)std::max<int64_t>(ng, 1) * 4, ctx->stream);
     hipMemsetAsync(db.str, 'N', (size_t)ctx->str_total, ctx->stream);
     hipMemsetAsync(db.gapctl, 0, (size_t)std::max<int64_t>(ng, 1) * 16, ctx->stream);
     hipEventRecord(ctx->ev0, ctx->stream);
@@ -687,6 +698,9 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);
     ctx->stats.place_calls = (int64_t)cnt[0];
     ctx->stats.alg_flops = (double)cnt[1];
+    ctx->stats.spec_flops = (double)cnt[2];
+    ctx->stats.mle_alg_flops = (double)cnt[3];
+    ctx->stats.mle_exec_flops = (double)cnt[4];
     // compact strings
     int64_t need = 0;
     for (int64_t g = 0; g < ng; g++) need += out->filled_len[g] > 0 ? out->filled_len[g] : 0;

@@ -41,6 +41,7 @@ FIG_D int fig_atomic_fetch_add_i32(int *p, int v) { int o = *p; *p += v; return 
 FIG_D void fig_atomic_min_i32(int *p, int v) { if (v < *p) *p = v; }
 FIG_D void fig_atomic_or_i32(int *p, int v) { *p |= v; }
 FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { *p += v; }
+FIG_D unsigned long long fig_shfl_down_u64(unsigned long long v, int off) { (void)v; (void)off; return 0; }   // one lane: nothing to the right
 #else
 #include <hip/hip_runtime.h>
 #define FIG_D __device__ static
@@ -61,6 +62,7 @@ FIG_D int fig_atomic_fetch_add_i32(int *p, int v) { return atomicAdd(p, v); }
 FIG_D void fig_atomic_min_i32(int *p, int v) { atomicMin(p, v); }
 FIG_D void fig_atomic_or_i32(int *p, int v) { atomicOr(p, v); }
 FIG_D void fig_atomic_add_u64(unsigned long long *p, unsigned long long v) { atomicAdd(p, v); }
+FIG_D unsigned long long fig_shfl_down_u64(unsigned long long v, int off) { return __shfl_down(v, off, 64); }
 #endif
 
 #define FIG_NOPOS 0x7fffffff
@@ -255,6 +257,8 @@ struct FigEng {
     unsigned char *gs;               // consensus codes of the gap columns for the MLE pass [capG]
     int capG;
     unsigned long long flops;        // per-lane algorithmic flop count
+    unsigned long long mle_alg;      // per-lane share of `flops` credited to the MLE passes (1 per placement and base)
+    unsigned long long mle_exec;     // FP64 multiplies the MLE passes actually executed after pruning (wave total, kept in lane 0)
     unsigned long long wait_cycles;  // FIG_PROF only: cycles spent in workgroup barriers
     unsigned long long prof[22];     // FIG_PROF only: phase timers
 };

@@ -613,7 +613,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         // reads per chunk; each wave stages its read's codes and its weight row, then all lanes add the chunk's rows
         // into the gap columns read by read (the reference's order), and lane 0 adds the per-read maxima in read order.
         unsigned char *const rb_keep = E.rb; double *const wbuf_keep = E.wbuf;
-        unsigned long long pfl = 0;                    // lane-local flop count of the partial passes
+        unsigned long long pfl = 0, pml = 0;           // lane-local flop count of the partial passes (pml: the MLE share)
         // a partial read has at most len-1 <= 199 placements, so its weight row needs 208 doubles, not a full Wcap row:
         // every wave gets a row whenever the weight area (nteams x Wcap) holds nw such rows
         int nrow = E.nw < FIG_PLB_TEAMS ? E.nw : FIG_PLB_TEAMS;
@@ -723,7 +723,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                     for (; j < j1u; j++) { const int b = (int)((pkr[j >> 4] >> ((j & 15) * 2)) & 3); const double c = cc[b * ncolE_u + j]; const double f = mtf[2 * j + 1] * c; t *= (c < 0 ? mtf[2 * j] : f); }
                 }
                 if (t > best.v) { best.v = t; best.o = o; }
-                pfl += (unsigned long long)(j1 - j0);
+                pfl += (unsigned long long)(j1 - j0); pml += (unsigned long long)(j1 - j0);
             }
             best = fig_wave_best(E, best);
             if (E.lane == 0 && p < prc) {
@@ -737,7 +737,8 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             }
         }
         E.rb = rb_keep;
-        E.flops += pfl;
+        E.flops += pfl; E.mle_alg += pml;
+        { unsigned long long t = pml; for (int off = 32; off > 0; off >>= 1) t += fig_shfl_down_u64(t, off); E.mle_exec += t; }   // unpruned: executed == credited
         FIG_SYNC();
         FIG_TICK(E, 5);
         if (E.tid == 0) {

@@ -323,15 +323,16 @@ FIG_D void fig_mblk_compute_n(const FigMBlk &B, int n, double &qa, double &qb) {
 FIG_D int fig_popc64(unsigned long long m) { int c = 0; for (; m; m &= m - 1) c++; return c; }
 #define FIG_M2P_CHECK(done) do { \
         ma = fig_ballot(va_ok && qa >= bound); mb = fig_ballot(vb_ok && qb >= bound); \
+        nb_done = (done); \
         if (!(ma | mb)) return 0; \
         if (allow_few) { const int alive_ = fig_popc64(ma) + fig_popc64(mb); if (alive_ <= 8 && (nblk - (done)) > 4 * alive_) return 1; } \
     } while (0)
 template <bool LDS, int DX>
 FIG_D int fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int len, int xa, int xb, bool va_ok, bool vb_ok,
-                            double bound, bool allow_few, double &qa, double &qb, unsigned long long &ma, unsigned long long &mb) {
+                            double bound, bool allow_few, double &qa, double &qb, unsigned long long &ma, unsigned long long &mb, int &nb_done) {
     const int nblk = (len + 7) >> 3;
     const int nlast = len - 8 * (nblk - 1);
-    ma = mb = 0;
+    ma = mb = 0; nb_done = nblk > 0 ? nblk : 0;
     if (nblk <= 0) return 2;
     FigMBlk A, Bk;
     fig_mblk_load<LDS, DX>(A, C, ncolE, pk, mt, 0, xa, xb);
@@ -350,6 +351,7 @@ FIG_D int fig_hot_chain_m2p(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt
         FIG_M2P_CHECK(bi + 1);
         fig_mblk_compute_n(Bk, nlast, qa, qb);
     } else fig_mblk_compute_n(A, nlast, qa, qb);
+    nb_done = nblk;
     return 2;
 }
 
@@ -857,6 +859,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
     unsigned long long fl_acc = 0;                   // lane-local flop count, added to E.flops once
+    unsigned long long ex_acc = 0;                   // wave-uniform: multiplies into placement products actually executed
     // per-wave factor buffer of fig_mle_serial: the weight rows are idle during the MLE pass
     double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
@@ -904,7 +907,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 if (h != FIG_NOPOS && h >= obase && h <= w.hi) {
                     r0 = (h - obase) / (2 * stride); if (r0 >= nrounds) r0 = 0;
                     if (use_serial) {
-                        const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, h + xoff, fbuf, lane, U.wsz);
+                        ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, h + xoff, fbuf, lane, U.wsz);
                         if (v > init) { ub.v = v; ub.o = h; bound = v; }
                     }
                 }
@@ -964,7 +967,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                             for (int q2 = 0; q2 < nwr; q2++) mmf += __builtin_amdgcn_readlane(mml, q2);
 #endif
                             if (mmf >= mcut_cur) continue;
-                            const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                            ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
                             if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
                             if (v > bound) { bound = v; mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
                         }
@@ -1019,7 +1022,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                             bm = fig_wave_best(E, bm);
                             const int o1 = fig_u(bm.o);
                             if (o1 != FIG_NOPOS) {
-                                const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, o1 + xoff, fbuf, lane, U.wsz);
+                                ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, o1 + xoff, fbuf, lane, U.wsz);
                                 if (v > init) { FigBest y; y.v = v; y.o = o1; ub = fig_best_merge(ub, y); }
                                 if (v > bound) bound = v;
                             }
@@ -1041,7 +1044,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                                         m &= m - 1;
                                         const int os = base_a + bit + (half ? stride : 0);
                                         if (os == ub.o) continue;                   // already evaluated
-                                        const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                                        ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
                                         if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
                                         if (v > bound) bound = v;
                                     }
@@ -1053,11 +1056,14 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     }
                     double qa = 1, qb = 1;
                     unsigned long long ma = 0, mb = 0;
+                    int nb_done = 0;
 #ifdef FIG_EMU
-                    const int rc = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb);
+                    const int rc = fig_hot_chain_m2p<LDS, 0>(C, ncolE, pk, mt, rs.len, xa, xb, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb, nb_done);
 #else
-                    const int rc = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, oa + xoff, 0, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb);
+                    const int rc = fig_hot_chain_m2p<LDS, 64>(C, ncolE, pk, mt, rs.len, oa + xoff, 0, va_ok, vb_ok, mono ? bound : -FIG_DBL_MAX * 2.0, use_serial && mono, qa, qb, ma, mb, nb_done);
 #endif
+                    { int steps_ = nb_done * 8; if (steps_ > rs.len) steps_ = rs.len;
+                      ex_acc += (unsigned long long)steps_ * (unsigned long long)(fig_popc64(fig_ballot(va_ok)) + fig_popc64(fig_ballot(vb_ok))); }
                     FIG_TICK(E, 16);
                     if (rc == 2) {
                         if (va_ok && (qa > best.v || (qa == best.v && best.o != FIG_NOPOS && oa < best.o))) { best.v = qa; best.o = oa; }
@@ -1073,7 +1079,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                                 m &= m - 1;
                                 const int os = base_a + bit + (half ? stride : 0);
                                 if (os == ub.o) continue;                       // already evaluated (the hint)
-                                const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                                ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
                                 if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
                                 if (v > bound) bound = v;
                             }
@@ -1085,7 +1091,10 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 if (lane == 0) best = fig_best_merge(best, ub);
                 o = w.hi + 1;
             }
-            for (; o <= w.hi; o += stride) {
+            for (; fig_wave_any(o <= w.hi); o += stride) {
+                const bool vo = o <= w.hi;
+                ex_acc += (unsigned long long)rs.len * (unsigned long long)fig_popc64(fig_ballot(vo));
+                if (!vo) continue;
                 double q = fig_hot_chain_m<LDS>(C, ncolE, pk, nw2, mt, rs.len, o + xoff);
                 if (q > best.v) { best.v = q; best.o = o; }
                 nplace++;
@@ -1142,7 +1151,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
         }
         FIG_TICK(E, 3);
     }
-    E.flops += fl_acc;
+    E.flops += fl_acc; E.mle_alg += fl_acc; E.mle_exec += ex_acc;
     FIG_SYNC();
     if (nci_lds) {
         for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = nl[j * nst + x];

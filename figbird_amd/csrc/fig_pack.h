@@ -110,6 +110,16 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
     if (ng < 0) return FIG_EINVAL;
     if (ng > 0 && (!b->gap_contig || !b->gap_start || !b->gap_len || !b->contig_off || !b->contig_seq || !b->p_read_off)) return FIG_EINVAL;
     if (m->unmapped_flag && ng > 0 && !b->u_read_off) return FIG_EINVAL;
+    // CSR ranges must be non-negative and non-decreasing, and the arrays behind a non-empty range present
+    if (ng > 0) {
+        if (b->p_read_off[0] < 0 || (m->unmapped_flag && b->u_read_off[0] < 0)) return FIG_EINVAL;
+        for (int64_t g = 0; g < ng; g++) {
+            if (b->p_read_off[g + 1] < b->p_read_off[g]) return FIG_EINVAL;
+            if (m->unmapped_flag && b->u_read_off[g + 1] < b->u_read_off[g]) return FIG_EINVAL;
+        }
+        if (b->p_read_off[ng] > 0 && (!b->p_seq_off || !b->p_seq || !b->p_pos || !b->p_match || !b->p_clipped_index || !b->p_ref_pos)) return FIG_EINVAL;
+        if (m->unmapped_flag && b->u_read_off[ng] > 0 && (!b->u_seq_off || !b->u_seq || !b->u_anchor_pos || !b->u_is_reverse)) return FIG_EINVAL;
+    }
     if (m->max_distance < m->max_read_length) return FIG_EUNSUP;       // placements must stay inside the +-D window
     K.n_gaps = ng;
     K.gaps.assign(ng, FigDevGap());
@@ -164,7 +174,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             if (n > FIG_READ_CAP + 1) n = FIG_READ_CAP + 1;              // every per-file loop stops after 3001 lines
             for (int64_t r = r0; r < r0 + n; r++) {
                 int len = (int)(b->p_seq_off[r + 1] - b->p_seq_off[r]);
-                if (len > FIG_MAX_READLEN || len < 1) return FIG_EUNSUP;
+                if (len > FIG_MAX_READLEN || len > m->max_read_length || len < 1) return FIG_EUNSUP;   // the {1-e,e} pair tables hold max_read_length entries
                 K.p_pos.push_back(b->p_pos[r]); K.p_aux.push_back(b->p_match[r]); K.p_clip.push_back(b->p_clipped_index[r]);
                 K.p_ref.push_back(b->p_ref_pos[r]); K.p_len.push_back(len);
                 K.p_woff.push_back((int64_t)K.packed.size());

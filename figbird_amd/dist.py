@@ -39,45 +39,92 @@ def estimate_cost(gap_len: np.ndarray, n_reads: np.ndarray, read_len: int, unmap
     return R * W * read_len * np.maximum(cand, 1.0) * its + 1.0
 
 
-def all_gather_results(ids: Sequence[int], filled_len: np.ndarray, gaptofill: np.ndarray, strings: Sequence[str], n_total: int,
-                       device=None) -> Tuple[np.ndarray, np.ndarray, List[str]]:
-    """All-gather the shard results: one fixed-size header exchange (counts, byte totals) and one padded payload
-    all-gather.  Returns (filled_len[n_total], gaptofill[n_total], strings[n_total]) on every rank."""
+def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None):
+    """All-gather the shard results as packed byte buffers: one 2-word header exchange, then ONE all-gather of a
+    single uint8 buffer per rank laid out [ids | filled_len | gaptofill | gap strings], straight from the numpy
+    arrays the C ABI filled (no per-gap Python strings on the way).  `res` is an api.FillResult (fields
+    filled_len, gaptofill, str_off, raw).  Returns (filled_len[n_total], gaptofill[n_total], strings) on every
+    rank, `strings` being a PackedStrings (bytes of gap g = strings[g]) in global gap order."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size() if dist.is_initialized() else 1
+    ids_a = np.asarray(ids, dtype=np.int32)
+    n = len(ids_a)
+    fl_a = np.asarray(res.filled_len[:n], dtype=np.int32)
+    gt_a = np.asarray(res.gaptofill[:n], dtype=np.int32)
+    nbytes = int(res.str_off[n]) if n else 0
+    payload = np.asarray(res.raw[:nbytes], dtype=np.uint8)
     if world == 1:
-        fl = np.zeros(n_total, dtype=np.int32); gt = np.zeros(n_total, dtype=np.int32); ss = [""] * n_total
-        for k, g in enumerate(ids):
-            fl[g] = filled_len[k]; gt[g] = gaptofill[k]; ss[g] = strings[k]
-        return fl, gt, ss
-    dev = device if device is not None else torch.device("cpu")
-    n = len(ids)
-    payload = "".join(strings).encode()
-    head = torch.tensor([n, len(payload)], dtype=torch.int64, device=dev)
-    heads = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(heads, head)
-    max_n = int(max(int(h[0]) for h in heads)); max_b = int(max(int(h[1]) for h in heads))
-    rec = torch.zeros(max_n * 3 + 1, dtype=torch.int32, device=dev)          # ids, filled_len, gaptofill
-    if n:
-        rec[:n] = torch.as_tensor(np.asarray(ids, dtype=np.int32), device=dev)
-        rec[max_n:max_n + n] = torch.as_tensor(np.asarray(filled_len, dtype=np.int32), device=dev)
-        rec[2 * max_n:2 * max_n + n] = torch.as_tensor(np.asarray(gaptofill, dtype=np.int32), device=dev)
-    buf = torch.zeros(max(max_b, 1), dtype=torch.uint8, device=dev)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8).to(dev)
-    recs = [torch.zeros_like(rec) for _ in range(world)]
-    bufs = [torch.zeros_like(buf) for _ in range(world)]
-    dist.all_gather(recs, rec)
-    dist.all_gather(bufs, buf)
-    fl = np.zeros(n_total, dtype=np.int32); gt = np.zeros(n_total, dtype=np.int32); ss = [""] * n_total
-    for r in range(world):
-        nr = int(heads[r][0])
-        rc = recs[r].cpu().numpy(); raw = bufs[r].cpu().numpy().tobytes()
-        o = 0
-        for k in range(nr):
-            g = int(rc[k]); L = int(rc[max_n + k])
-            fl[g] = L; gt[g] = int(rc[2 * max_n + k])
-            ss[g] = raw[o:o + max(L, 0)].decode(); o += max(L, 0)
-    return fl, gt, ss
+        heads = [(n, nbytes)]
+        blobs = [(ids_a, fl_a, gt_a, payload)]
+    else:
+        dev = device if device is not None else torch.device("cpu")
+        head = torch.tensor([n, nbytes], dtype=torch.int64, device=dev)
+        hs = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(hs, head)
+        heads = [(int(h[0]), int(h[1])) for h in hs]
+        max_n = max(h[0] for h in heads); max_b = max(h[1] for h in heads)
+        size = 12 * max_n + max_b + 8
+        mine = np.zeros(size, dtype=np.uint8)
+        mine[0:4 * n] = ids_a.view(np.uint8)
+        mine[4 * max_n:4 * max_n + 4 * n] = fl_a.view(np.uint8)
+        mine[8 * max_n:8 * max_n + 4 * n] = gt_a.view(np.uint8)
+        mine[12 * max_n:12 * max_n + nbytes] = payload
+        buf = torch.from_numpy(mine).to(dev)
+        bufs = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(bufs, buf)
+        blobs = []
+        for r in range(world):
+            a = bufs[r].cpu().numpy()
+            nr, nb = heads[r]
+            blobs.append((a[0:4 * nr].view(np.int32), a[4 * max_n:4 * max_n + 4 * nr].view(np.int32),
+                          a[8 * max_n:8 * max_n + 4 * nr].view(np.int32), a[12 * max_n:12 * max_n + nb]))
+    gid = np.concatenate([b[0] for b in blobs]) if blobs else np.zeros(0, dtype=np.int32)
+    flc = np.concatenate([b[1] for b in blobs]); gtc = np.concatenate([b[2] for b in blobs])
+    pay = np.concatenate([b[3] for b in blobs])
+    lens = np.maximum(flc, 0).astype(np.int64)
+    src_start = np.cumsum(lens) - lens
+    fl = np.zeros(n_total, dtype=np.int32); gt = np.zeros(n_total, dtype=np.int32)
+    fl[gid] = flc; gt[gid] = gtc
+    glens = np.zeros(n_total, dtype=np.int64); glens[gid] = lens
+    off = np.zeros(n_total + 1, dtype=np.int64); off[1:] = np.cumsum(glens)
+    perm = np.argsort(gid, kind="stable")
+    total = int(off[-1])
+    idx = np.repeat(src_start[perm] - off[:-1][gid[perm]], lens[perm]) + np.arange(total, dtype=np.int64)
+    raw = pay[idx] if total else np.zeros(0, dtype=np.uint8)
+    return fl, gt, PackedStrings(off, raw)
+
+
+class PackedStrings:
+    """Gap strings of a whole gap set in one byte buffer (global gap order)."""
+
+    def __init__(self, off: np.ndarray, raw: np.ndarray):
+        self.off, self.raw = off, raw
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, g: int) -> bytes:
+        return self.raw[self.off[g]:self.off[g + 1]].tobytes()
+
+    def __iter__(self):
+        return (self[g] for g in range(len(self)))
+
+    def filled_bases(self) -> int:
+        return int(len(self.raw) - np.count_nonzero(self.raw == ord("N")))
+
+    def to_list(self) -> List[str]:
+        return [self[g].decode() for g in range(len(self))]
+
+
+def all_gather_results(ids: Sequence[int], filled_len: np.ndarray, gaptofill: np.ndarray, strings: Sequence[str], n_total: int,
+                       device=None) -> Tuple[np.ndarray, np.ndarray, List[str]]:
+    """String-list face of all_gather_packed (kept for callers that hold Python strings)."""
+    from types import SimpleNamespace
+    raw = np.frombuffer("".join(strings).encode() or b"\0", dtype=np.uint8)
+    off = np.zeros(len(strings) + 1, dtype=np.int64)
+    off[1:] = np.cumsum([len(s) for s in strings])
+    res = SimpleNamespace(filled_len=np.asarray(filled_len, dtype=np.int32), gaptofill=np.asarray(gaptofill, dtype=np.int32), str_off=off, raw=raw)
+    fl, gt, ps = all_gather_packed(ids, res, n_total, device=device)
+    return fl, gt, ps.to_list()

@@ -39,7 +39,7 @@ typedef struct fig_ctx fig_ctx;
 /* Model tables = the globals Figbird.cpp builds once per run from myout.sam / stat.txt
  * (A0: Figbird.cpp:47-91, built :846-921, :291-487, :497-844, :1156-1376, :7155-7200),
  * plus the run-level argv of Figbird.cpp main (:6957-6973).  Built on the host by the
- * caller (figfill does it in figbird_amd/csrc/host/fig_model.cpp). */
+ * caller (figfill does it in figbird_amd/csrc/host/fig_host.cpp: build_model). */
 typedef struct fig_model {
     int32_t max_read_length;            /* maxReadLength (stat.txt col 3), <= 200            */
     const double *error_pos_dist;       /* errorPosDist[max_read_length]                    */
@@ -123,6 +123,10 @@ typedef struct fig_stats {
     int64_t place_calls;                /* placeReads invocations executed on the device     */
     double alg_flops;                   /* algorithmic FP64 flops, counted on device */
     int32_t n_launches;
+    int32_t pad0;
+    double spec_flops;                  /* algorithmic flops of every candidate evaluation executed, discarded speculation included */
+    double mle_alg_flops;               /* share of the executed evaluations' flops credited to the MLE passes (1 per placement and base) */
+    double mle_exec_flops;              /* FP64 multiplies the MLE passes really executed (exact pruning skips the rest) */
 } fig_stats;
 
 int fig_version(void);
@@ -130,6 +134,8 @@ const char *fig_strerror(int code);
 
 int fig_ctx_create(int device_ordinal, fig_ctx **out);
 void fig_ctx_destroy(fig_ctx *ctx);
+/* Sets the run-level model.  A batch left resident by fig_batch_upload is DROPPED (it was packed under the previous
+ * model: launch classes, capacities and candidate ranges depend on it); upload again before fig_fill_resident. */
 int fig_ctx_set_model(fig_ctx *ctx, const fig_model *model);
 
 /* Worst-case bytes of results->str for this batch (sum of per-gap alloc_arg, Figbird.cpp:7395-7398). */

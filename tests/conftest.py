@@ -17,12 +17,10 @@ def _built():
     """Build (or reuse) the native artefacts once per session.  On the GPU box everything is prebuilt and
     travels with the snapshot; here it compiles in well under a minute."""
     from figbird_amd import build as fbuild
-    need_hip = not os.path.exists(fbuild.LIB)
-    try:
-        if need_hip:
-            fbuild.build_lib()
-        fbuild.build_figfill()
-        fbuild.build_test_infra()
-    except Exception as e:  # pragma: no cover - surfaced by the tests that need the artefact
-        print("build failed:", e)
+    # build_lib() is a no-op when libfighip.so is newer than every source under csrc/; a stale or failing build fails the
+    # session, so a green run always means HEAD's kernels were the ones tested
+    fbuild.build_lib()
+    fbuild.build_figfill()
+    from tools import build_test_infra
+    build_test_infra.build()
     yield

@@ -48,6 +48,7 @@ extern "C" int fig_ctx_set_model(fig_ctx *ctx, const fig_model *m) {
     if (!ctx || !m) return FIG_EINVAL;
     if (m->max_read_length <= 0 || m->max_read_length > FIG_MAX_READLEN) return FIG_EUNSUP;
     if (m->partial_flag && m->unmapped_flag) return FIG_EUNSUP;
+    fig_batch_free(ctx);                 // as libfighip: a resident batch was packed under the previous model
     int L = m->max_read_length;
     ctx->hm = *m;
     ctx->e.assign(m->error_pos_dist, m->error_pos_dist + L);
@@ -126,7 +127,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         fig_lds = lds.data();
         FigEng E;
         E.tid = 0; E.nt = 1; E.lane = 0; E.wave = 0; E.nw = 1; E.wsz = 1;
-        E.M = &ctx->dm; E.B = &B; E.capG = c.capG; E.flops = 0;
+        E.M = &ctx->dm; E.B = &B; E.capG = c.capG; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0;
         E.ncolE = c.ncolE; E.xoff = M.L - 1; E.Wcap = c.Wcap; E.nteams = nteams;
         fig_scratch_layout(slab.data(), K.capG, K.capR, K.capP, K.capC, K.capW, K.capE, &E.scr);
         E.pq_lds = 1; E.w_lds = 1;
@@ -191,9 +192,10 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
                 fig_gap_end<true>(E);
             }
         }
-        counters[1] += E.flops;
+        counters[1] += E.flops; counters[3] += E.mle_alg; counters[4] += E.mle_exec;
     }
     ctx->stats.place_calls = (int64_t)counters[0]; ctx->stats.alg_flops = (double)counters[1];
+    ctx->stats.spec_flops = (double)counters[1]; ctx->stats.mle_alg_flops = (double)counters[3]; ctx->stats.mle_exec_flops = (double)counters[4];
     ctx->stats.packed_bytes = K.packed_bytes(); ctx->stats.n_launches = (int)K.classes.size();
     int64_t need = 0;
     for (int64_t g = 0; g < ng; g++) { out->filled_len[g] = fl[g]; out->gaptofill[g] = gtf[g]; need += fl[g] > 0 ? fl[g] : 0; }

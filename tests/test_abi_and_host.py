@@ -95,7 +95,7 @@ def test_emulation_library_through_the_python_api(tmp_path):
                                  partial_flag=int(a[4]), unmapped_flag=int(a[5]), script_itr=int(a[3]), max_distance=int(a[1]),
                                  read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
     case = synth.make_case(name, 2, "partial", [(3000, 30), (6000, 120), (9000, 10)], insert_mean=180, insert_sd=10, coverage=30, n_model_pairs=800)
-    eng = api.Engine(0, lib_path=fbuild.EMULIB)
+    eng = api.Engine(0, lib_path=util.EMULIB)
     eng.set_model(model)
     res = eng.fill(synth.case_to_batch(case))
     eng.close()

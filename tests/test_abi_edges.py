@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from figbird_amd import api, build as fbuild, synth
+from figbird_amd import api, synth
 from tests import util
 
 
@@ -53,6 +53,30 @@ def _edge_checks(lib_path, tmp_path):
     bad.u_seq = np.concatenate([np.full(400, ord("A"), dtype=np.uint8), batch.u_seq])
     with pytest.raises(RuntimeError, match="supported envelope"):
         eng.fill(bad)
+    # a partial (soft-clipped) read longer than the model's max_read_length would index the {1-e,e} pair tables past
+    # their end -> FIG_EUNSUP (the frag-library reads of this batch are 101 bp; the model's L is 150)
+    bad = copy.copy(batch)
+    npr = len(batch.p_seq_off) - 1
+    if npr > 0:
+        bad.p_seq_off = batch.p_seq_off.copy(); bad.p_seq_off[1:] += 60        # first partial read: 161 bp > L = 150
+        bad.p_seq = np.concatenate([np.full(60, ord("A"), dtype=np.uint8), batch.p_seq])
+        bad.p_qual = np.concatenate([np.full(60, ord("I"), dtype=np.uint8), batch.p_qual])
+        with pytest.raises(RuntimeError, match="supported envelope"):
+            eng.fill(bad)
+    # CSR offsets that go backwards -> FIG_EINVAL (would give a negative read count in the gap descriptor)
+    bad = copy.copy(batch)
+    bad.u_read_off = batch.u_read_off.copy(); bad.u_read_off[2] = bad.u_read_off[1] - 1 if bad.u_read_off[1] > 0 else -1
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        eng.fill(bad)
+    bad = copy.copy(batch)
+    bad.p_read_off = batch.p_read_off.copy(); bad.p_read_off[0] = -3
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        eng.fill(bad)
+    # a new model drops the resident batch (it was packed under the old one): fill_resident must refuse, not run stale
+    eng.upload(batch)
+    eng.set_model(eng._model)
+    with pytest.raises(RuntimeError, match="invalid argument"):
+        eng.fill_resident()
     # the engine is still usable after the errors and gives the same answer as before them
     r1 = eng.fill(batch)
     r2 = eng.fill(batch)
@@ -61,7 +85,7 @@ def _edge_checks(lib_path, tmp_path):
 
 
 def test_abi_edges_on_the_emulation_library(tmp_path):
-    _edge_checks(fbuild.EMULIB, tmp_path)
+    _edge_checks(util.EMULIB, tmp_path)
 
 
 @pytest.mark.gpu

@@ -38,7 +38,7 @@ def _worker(rank, world, port, root, q):
         sub = synth.subset_batch(full, mine)
         model = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
                                      partial_flag=1, unmapped_flag=0, script_itr=1, max_distance=180, read_length=50, neg_overlap=30, partial_len=50)
-        eng = api.Engine(0, lib_path=fbuild.EMULIB)
+        eng = api.Engine(0, lib_path=util.EMULIB)
         eng.set_model(model)
         res = eng.fill(sub)
         eng.close()

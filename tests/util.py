@@ -10,12 +10,14 @@ import tarfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-from figbird_amd import build as fbuild  # noqa: E402
+from figbird_amd import build as pbuild  # noqa: E402
+from tools import build_test_infra as fbuild  # noqa: E402
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 ORACLE = fbuild.ORACLE
 EMU = fbuild.EMU
-FIGFILL = fbuild.FIGFILL
+EMULIB = fbuild.EMULIB
+FIGFILL = pbuild.FIGFILL
 REF_FIGBIRD = os.path.join(fbuild.REFDIR, "Figbird.out")
 
 GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz")) if os.path.isdir(GOLDEN) else []
