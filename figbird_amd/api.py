@@ -52,6 +52,7 @@ class FigGapResults(C.Structure):
         ("dbg_max_cand", C.c_int32), ("dbg_n_cand", c_i32_p), ("dbg_cand_i", c_i32_p), ("dbg_cand_lik", c_double_p),
         ("dbg_n_place", c_i32_p),
         ("draw_pos", c_i32_p), ("draw_isz", c_i32_p), ("draw_len", c_i32_p),
+        ("dbg_plane_cols", C.c_int32), ("dbg_plane_reads", C.c_int32), ("dbg_counts", c_double_p), ("dbg_read_maxlv", c_double_p),
     ]
 
 
@@ -241,6 +242,8 @@ class FillResult:
     strings: List[str]
     cand: Optional[list] = None     # per gap: list of (gapEstimate, iterations, valid_count, likelihood)
     n_place: Optional[np.ndarray] = None
+    counts: Optional[np.ndarray] = None    # plane (i): [n_gaps, debug_cand, plane_cols, 5] countsGap after the candidate's last E-step
+    read_maxlv: Optional[np.ndarray] = None  # plane (ii): [n_gaps, debug_cand, plane_reads] per-read E-step maximum
     str_off: Optional[np.ndarray] = None   # int64[n+1]: gap g's string is raw[str_off[g]:str_off[g+1]]
     raw: Optional[np.ndarray] = None       # uint8: all gap strings back to back, as the C ABI wrote them
 
@@ -283,7 +286,7 @@ class Engine:
         self.cap = int(self.lib.fig_results_capacity(C.byref(self._cm), C.byref(self._cb)))
         self._check(self.lib.fig_batch_upload(self.ctx, C.byref(self._cb)), "fig_batch_upload")
 
-    def fill_resident(self, debug_cand: int = 0) -> FillResult:
+    def fill_resident(self, debug_cand: int = 0, plane_cols: int = 0, plane_reads: int = 0) -> FillResult:
         n = self.n_gaps
         fl = np.zeros(max(n, 1), dtype=np.int32); gt = np.zeros(max(n, 1), dtype=np.int32)
         so = np.zeros(n + 1, dtype=np.int64); st = np.zeros(max(self.cap, 1), dtype=np.uint8)
@@ -295,6 +298,12 @@ class Engine:
             dl = np.zeros(max(n, 1) * debug_cand)
             dp = np.zeros(max(n, 1), dtype=np.int32)
             r.dbg_max_cand = debug_cand; r.dbg_n_cand = _p(dn, c_i32_p); r.dbg_cand_i = _p(di, c_i32_p); r.dbg_cand_lik = _p(dl, c_double_p); r.dbg_n_place = _p(dp, c_i32_p)
+            if plane_cols > 0:
+                pc = np.zeros((max(n, 1), debug_cand, plane_cols, 5))
+                r.dbg_plane_cols = plane_cols; r.dbg_counts = _p(pc, c_double_p)
+            if plane_reads > 0:
+                pr = np.zeros((max(n, 1), debug_cand, plane_reads))
+                r.dbg_plane_reads = plane_reads; r.dbg_read_maxlv = _p(pr, c_double_p)
         self._check(self.lib.fig_fill_resident(self.ctx, C.byref(r)), "fig_fill_resident")
         raw = st.tobytes()
         strings = [raw[so[g]:so[g + 1]].decode() for g in range(n)]
@@ -307,15 +316,19 @@ class Engine:
                 cand.append([(int(di[(base + j) * 3]), int(di[(base + j) * 3 + 1]), int(di[(base + j) * 3 + 2]), float(dl[base + j])) for j in range(k)])
         res = FillResult(fl[:n].copy(), gt[:n].copy(), strings, cand, str_off=so, raw=st)
         res.n_place = dp[:n].copy() if debug_cand > 0 else None
+        if debug_cand > 0 and plane_cols > 0:
+            res.counts = pc[:n]
+        if debug_cand > 0 and plane_reads > 0:
+            res.read_maxlv = pr[:n]
         return res
 
     def free_batch(self):
         self.lib.fig_batch_free(self.ctx)
 
-    def fill(self, batch: GapBatch, debug_cand: int = 0) -> FillResult:
+    def fill(self, batch: GapBatch, debug_cand: int = 0, plane_cols: int = 0, plane_reads: int = 0) -> FillResult:
         self.upload(batch)
         try:
-            return self.fill_resident(debug_cand)
+            return self.fill_resident(debug_cand, plane_cols, plane_reads)
         finally:
             self.free_batch()
 

@@ -600,6 +600,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     auto tfree = [&]() { for (void *p : tmp) hipFree(p); };
     db.dbg_n_cand = nullptr; db.dbg_cand_i = nullptr; db.dbg_cand_lik = nullptr; db.dbg_max_cand = 0; db.dbg_n_place = nullptr;
     db.draw_pos = db.draw_isz = db.draw_len = nullptr;
+    db.dbg_counts = db.dbg_read_maxlv = nullptr; db.dbg_plane_cols = db.dbg_plane_reads = 0;
     void *p;
     if (out->dbg_n_cand && out->dbg_cand_i && out->dbg_cand_lik && out->dbg_max_cand > 0) {
         db.dbg_max_cand = out->dbg_max_cand;
@@ -608,6 +609,16 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         if (talloc((size_t)ng * out->dbg_max_cand * 8, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_cand_lik = (double *)p;
         hipMemsetAsync(db.dbg_n_cand, 0, (size_t)ng * 4, ctx->stream);
         if (out->dbg_n_place) { if (talloc((size_t)ng * 4, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_n_place = (int32_t *)p; hipMemsetAsync(db.dbg_n_place, 0, (size_t)ng * 4, ctx->stream); }
+        if (out->dbg_counts && out->dbg_plane_cols > 0) {
+            const size_t n = (size_t)ng * out->dbg_max_cand * out->dbg_plane_cols * 5 * 8;
+            if (talloc(n, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_counts = (double *)p; db.dbg_plane_cols = out->dbg_plane_cols;
+            hipMemsetAsync(db.dbg_counts, 0, n, ctx->stream);
+        }
+        if (out->dbg_read_maxlv && out->dbg_plane_reads > 0) {
+            const size_t n = (size_t)ng * out->dbg_max_cand * out->dbg_plane_reads * 8;
+            if (talloc(n, &p)) { tfree(); return FIG_ENOMEM; } db.dbg_read_maxlv = (double *)p; db.dbg_plane_reads = out->dbg_plane_reads;
+            hipMemsetAsync(db.dbg_read_maxlv, 0, n, ctx->stream);
+        }
     }
     int64_t nr = ctx->n_ureads + ctx->n_preads;
     if (out->draw_pos && out->draw_isz && out->draw_len) {
@@ -675,6 +686,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         hipMemcpyAsync(out->dbg_cand_i, db.dbg_cand_i, (size_t)ng * out->dbg_max_cand * 12, hipMemcpyDeviceToHost, ctx->stream);
         hipMemcpyAsync(out->dbg_cand_lik, db.dbg_cand_lik, (size_t)ng * out->dbg_max_cand * 8, hipMemcpyDeviceToHost, ctx->stream);
         if (db.dbg_n_place) hipMemcpyAsync(out->dbg_n_place, db.dbg_n_place, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (db.dbg_counts) hipMemcpyAsync(out->dbg_counts, db.dbg_counts, (size_t)ng * out->dbg_max_cand * out->dbg_plane_cols * 5 * 8, hipMemcpyDeviceToHost, ctx->stream);
+        if (db.dbg_read_maxlv) hipMemcpyAsync(out->dbg_read_maxlv, db.dbg_read_maxlv, (size_t)ng * out->dbg_max_cand * out->dbg_plane_reads * 8, hipMemcpyDeviceToHost, ctx->stream);
     }
     if (db.draw_pos) {
         hipMemcpyAsync(out->draw_pos, db.draw_pos, (size_t)nr * 4, hipMemcpyDeviceToHost, ctx->stream);

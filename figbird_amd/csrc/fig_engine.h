@@ -148,6 +148,7 @@ struct FigState {
     FigLoop L;
     // useful-work counters of this gap (speculative candidates that are discarded never reach them)
     unsigned long long flops_useful; int n_place, pad_np;
+    int dbg_j, pad_dj;               // candidate index whose numeric planes are being exported (-1: none)
 };
 
 struct FigTrip { int v[3]; };

@@ -584,6 +584,28 @@ FIG_D void fig_seed_reweight(FigEng &E) {
 
 #include "fig_engine_hot.h"
 
+// Numeric planes (i)/(ii) of the parity contract for the candidate being evaluated (parity tests only; all lanes).
+FIG_D void fig_dbg_planes(FigEng &E, int nreads) {
+    const FigDevBatch &B = *E.B;
+    if (!B.dbg_counts && !B.dbg_read_maxlv) return;
+    FIG_SYNC();
+    const int j = E.S->dbg_j;
+    if (j >= 0 && j < B.dbg_max_cand) {
+        const long long rec = (long long)E.g->gapNo * B.dbg_max_cand + j;
+        if (B.dbg_counts) {
+            int n = E.S->ncols < B.dbg_plane_cols ? E.S->ncols : B.dbg_plane_cols;
+            double *dst = B.dbg_counts + rec * B.dbg_plane_cols * 5;
+            for (int x = E.tid; x < n; x += E.nt) for (int b = 0; b < 5; b++) dst[(long long)x * 5 + b] = E.scr.cnt[b * E.capG + x];
+        }
+        if (B.dbg_read_maxlv) {
+            int n = nreads < B.dbg_plane_reads ? nreads : B.dbg_plane_reads;
+            double *dst = B.dbg_read_maxlv + rec * B.dbg_plane_reads;
+            for (int r = E.tid; r < n; r += E.nt) dst[r] = E.scr.maxlv[r];
+        }
+    }
+    FIG_SYNC();
+}
+
 // ---------------------------------------------------------------------------------------
 // placeReads, Figbird.cpp:3022-4387.  Returns maxLikelihood in S.lik (after a barrier).
 template <bool LDS>
@@ -668,11 +690,13 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * rstride;
                 fig_accumulate_columns(E, S.tm_len[t], S.tm_lo[t], S.tm_hi[t], G);
                 if (E.tid == 0 && S.wv_o[t] != FIG_NOPOS) maxLikelihood += S.wv_v[t];
+                if (E.tid == 0 && E.B->dbg_read_maxlv) E.scr.maxlv[p0 + t] = S.wv_o[t] != FIG_NOPOS ? S.wv_v[t] : 0.0;   // parity plane (ii); unused otherwise
             }
             FIG_SYNC();
         }
         E.rb = rb_keep; E.wbuf = wbuf_keep;
         FIG_TICK(E, 4);
+        fig_dbg_planes(E, nproc);
         // ---- MLE pass over the partial reads (:3267-3523)
         int prc = S.partial_read_count;
         for (int i = E.tid; i < prc; i += E.nt) {
@@ -756,6 +780,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         FIG_TICK(E, 4);
         fig_hot_estep_dispatch<LDS>(E, gapoffset);
         FIG_TICK(E, 5);
+        fig_dbg_planes(E, nU);
         // ---- consensus + MLE pass (:3694-3914)
         fig_compute_sequence(E, 0, 0);
         for (int x = E.tid; x < S.ncols; x += E.nt) E.gs[x] = E.scr.cons[x];

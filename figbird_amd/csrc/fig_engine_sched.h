@@ -24,7 +24,7 @@ FIG_D void fig_gap_begin(FigEng &E) {
         S.gl_len = S.gr_len = S.pl_len = S.pr_len = 0;
         S.cons_len = 1; E.scr.cons[0] = 4;
         S.best_len = S.cur_len = S.prev_len = S.orig_len = 0;
-        S.flops_useful = 0; S.n_place = 0;
+        S.flops_useful = 0; S.n_place = 0; S.dbg_j = -1; S.pad_dj = 0;
         fig_flank_tables(E);
         if (E.B->dbg_n_cand) E.B->dbg_n_cand[g.gapNo] = 0;
         if (E.B->draw_len) { E.B->draw_len[(long long)g.gapNo * 2] = -1; E.B->draw_len[(long long)g.gapNo * 2 + 1] = -1; }
@@ -102,12 +102,12 @@ FIG_D void fig_eval_candidate(FigEng &E) {
     const int G0 = E.g->G0;
     const int gapEstimate = S.L.gapEstimate, j = S.L.j, inr = S.L.inr, finalize_flag = S.L.finalize_flag;
     FIG_SYNC();
-    if (E.tid == 0) { S.umaxleftf = S.umaxrightf = S.ucoverf = 0; S.L.ev_side_break = 0; S.L.ev_iters = 0; }
+    if (E.tid == 0) { S.umaxleftf = S.umaxrightf = S.ucoverf = 0; S.L.ev_side_break = 0; S.L.ev_iters = 0; S.dbg_j = j; }
     int fill = fig_initialize(E, gapEstimate, j);
-    if (S.side_limit < 10) { if (E.tid == 0) { S.L.ev_side_break = 1; S.L.ev_fill = fill; } FIG_SYNC(); return; }
+    if (S.side_limit < 10) { if (E.tid == 0) { S.L.ev_side_break = 1; S.L.ev_fill = fill; S.dbg_j = -1; } FIG_SYNC(); return; }
     if (S.one_side_repeat_flag == 1) fill = 0;
     if (E.tid == 0) S.L.ev_fill = fill;
-    if (fill != 0 && inr) { FIG_SYNC(); return; }
+    if (fill != 0 && inr) { if (E.tid == 0) S.dbg_j = -1; FIG_SYNC(); return; }
     int i = 0;
     if (E.tid == 0) { S.discont_or_not = 0; S.comp_count = 0; S.overlap_threshold = 5; S.lik = S.L.likelihood; }
     FIG_SYNC();
@@ -129,7 +129,7 @@ FIG_D void fig_eval_candidate(FigEng &E) {
         fig_place_reads<LDS>(E, i, 1, gapEstimate - G0, 0);
     }
     fig_compute_sequence(E, 0, 0);
-    if (E.tid == 0) { S.L.likelihood = S.lik; S.L.ev_iters = i; }
+    if (E.tid == 0) { S.L.likelihood = S.lik; S.L.ev_iters = i; S.dbg_j = -1; }
     FIG_SYNC();
 }
 

@@ -65,6 +65,7 @@ struct FigDevBatch {
     int32_t *filled_len, *gaptofill; char *str;
     int32_t dbg_max_cand; int32_t *dbg_n_cand; int32_t *dbg_cand_i; double *dbg_cand_lik; int32_t *dbg_n_place;
     int32_t *draw_pos, *draw_isz, *draw_len; int64_t n_ureads;
+    int32_t dbg_plane_cols, dbg_plane_reads; double *dbg_counts, *dbg_read_maxlv;   // numeric planes (i)/(ii), parity tests only
     // work queue + counters
     int32_t *queue_head;             // [1] next index into order[]
     unsigned long long *counters;    // [0] placeReads calls, [1] algorithmic flops (as integer count)

@@ -129,9 +129,32 @@ def _qual(n: int) -> str:
     return "I" * n  # flat Q40
 
 
+def _indel_read(rng, genome: str, p: int, L: int, err: float) -> Tuple[str, str, str]:
+    """A read of length L aligned at genome[p:] with ONE insertion or deletion of 1-3 bases away from its ends, plus
+    substitution errors: (seq, CIGAR, MD) in Bowtie2's conventions (what processErrorTypes walks, Figbird.cpp:291-487)."""
+    k = int(rng.integers(1, 4))
+    a = int(rng.integers(8, L - 8 - k))
+    if rng.random() < 0.5:                                   # insertion: aMkI(L-a-k)M
+        ref = genome[p:p + L - k]
+        left, _ = _mutate(rng, ref[:a], err)
+        right, _ = _mutate(rng, ref[a:], err)
+        seq = left + _rand_seq(rng, k) + right
+        cigar = f"{a}M{k}I{L - a - k}M"
+        md = _md_tag(ref, left + right)
+    else:                                                    # deletion: aMkD(L-a)M, MD "<..>^DEL<..>"
+        ref_l, dele, ref_r = genome[p:p + a], genome[p + a:p + a + k], genome[p + a + k:p + L + k]
+        left, _ = _mutate(rng, ref_l, err)
+        right, _ = _mutate(rng, ref_r, err)
+        seq = left + right
+        cigar = f"{a}M{k}D{L - a}M"
+        md = _md_tag(ref_l, left) + "^" + dele + _md_tag(ref_r, right)[5:]
+    return seq, cigar, md
+
+
 def _model_pairs(rng, genome: str, contig_idx: int, n_pairs: int, L: int,
-                 mu: float, sd: float, err: float, forbid: List[Tuple[int, int]]) -> List[str]:
-    """Properly-paired reads for myout.sam (both mates fully inside N-free sequence)."""
+                 mu: float, sd: float, err: float, forbid: List[Tuple[int, int]], indel_rate: float = 0.0) -> List[str]:
+    """Properly-paired reads for myout.sam (both mates fully inside N-free sequence).  `indel_rate` > 0 gives that
+    share of the mates an insertion or deletion (CIGAR I/D + MD ^), which feed inPosDist/delPosDist."""
     lines = []
     n = len(genome)
     made = 0
@@ -151,13 +174,20 @@ def _model_pairs(rng, genome: str, contig_idx: int, n_pairs: int, L: int,
             continue
         ref1 = genome[p:p + L]
         ref2 = genome[p + isz - L:p + isz]
-        r1, _ = _mutate(rng, ref1, err)
-        r2, _ = _mutate(rng, ref2, err)
+        c1 = c2 = f"{L}M"
+        if indel_rate > 0 and rng.random() < indel_rate and p + L + 4 < n:
+            r1, c1, md1 = _indel_read(rng, genome, p, L, err)
+        else:
+            r1, _ = _mutate(rng, ref1, err); md1 = _md_tag(ref1, r1)
+        if indel_rate > 0 and rng.random() < indel_rate and p + isz + 4 < n:
+            r2, c2, md2 = _indel_read(rng, genome, p + isz - L, L, err)
+        else:
+            r2, _ = _mutate(rng, ref2, err); md2 = _md_tag(ref2, r2)
         q = f"m{contig_idx}_{made}"
-        lines.append("\t".join([q, "99", str(contig_idx), str(p + 1), f"{L}M", str(isz), r1,
-                                _qual(L), _md_tag(ref1, r1), "IH:i:1"]))
-        lines.append("\t".join([q, "147", str(contig_idx), str(p + isz - L + 1), f"{L}M",
-                                str(-isz), r2, _qual(L), _md_tag(ref2, r2), "IH:i:1"]))
+        lines.append("\t".join([q, "99", str(contig_idx), str(p + 1), c1, str(isz), r1,
+                                _qual(L), md1, "IH:i:1"]))
+        lines.append("\t".join([q, "147", str(contig_idx), str(p + isz - L + 1), c2,
+                                str(-isz), r2, _qual(L), md2, "IH:i:1"]))
         made += 1
     return lines
 
@@ -171,7 +201,8 @@ def make_case(name: str, seed: int, mode: str, gap_specs: List[Tuple[int, int]],
               frag_mean: float = 180.0, frag_sd: float = 10.0,
               neg_overlap_gaps: Optional[dict] = None,
               read_n_rate: float = 0.0,
-              max_reads_per_gap: int = 3000) -> Case:
+              max_reads_per_gap: int = 3000,
+              model_indel_rate: float = 0.0) -> Case:
     """One scaffold with gaps at `gap_specs` = [(start0_in_truth, true_len), ...].
 
     mode "unmapped": jump library N(insert_mean, insert_sd) -> gaps_<g>.sam (+ frag-library
@@ -218,7 +249,7 @@ def make_case(name: str, seed: int, mode: str, gap_specs: List[Tuple[int, int]],
         return ss + nrun + (tpos - te)
 
     forbid = [(ts - 1, max(te, ts) + 1) for ts, te, _, _ in truth_to_scaf]
-    myout = _model_pairs(rng, truth, 0, n_model_pairs, L, insert_mean, insert_sd, err, forbid)
+    myout = _model_pairs(rng, truth, 0, n_model_pairs, L, insert_mean, insert_sd, err, forbid, model_indel_rate)
     # NB: model pairs carry truth coordinates; positions only feed tlen statistics (col 6),
     # so the small truth/scaffold offset is irrelevant to the model.
 

@@ -113,6 +113,16 @@ typedef struct fig_gap_results {
     int32_t *draw_pos;                  /* [n_ureads + n_preads] maxPos-left_maxDistance, or INT32_MIN if the read was not drawn */
     int32_t *draw_isz;                  /* [n_ureads + n_preads] mleInsertSize / newInsertSize */
     int32_t *draw_len;                  /* [n_gaps*2] length argument of the unmapped / partial "S" header, -1 if absent */
+    /* optional numeric planes of the parity contract (SURVEY.md §8 preamble), per gap and candidate INDEX j (candidate
+     * length = gapMin + j; needs the dbg_cand buffers above; NULL to disable):
+     *  (i)  countsGap[x][0..4] as the E-step of the candidate's LAST placeReads call left it (Figbird.cpp:3181-3187 /
+     *       :3603-3611), x < min(candidate length, dbg_plane_cols);
+     *  (ii) per read, the E-step's maximum log-likelihood over its placements, maxlikelihood_value[r] (:3258-3261 /
+     *       :3680-3688; 0 when the read had no placement), r < min(reads of the gap, dbg_plane_reads). */
+    int32_t dbg_plane_cols;
+    int32_t dbg_plane_reads;
+    double *dbg_counts;                 /* [n_gaps*dbg_max_cand*dbg_plane_cols*5]           */
+    double *dbg_read_maxlv;             /* [n_gaps*dbg_max_cand*dbg_plane_reads]            */
 } fig_gap_results;
 
 /* Timing/occupancy facts of the last fig_fill_gaps call (for bench.py). */

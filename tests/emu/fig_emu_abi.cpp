@@ -106,6 +106,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         B.dbg_max_cand = out->dbg_max_cand; B.dbg_n_cand = out->dbg_n_cand; B.dbg_cand_i = out->dbg_cand_i; B.dbg_cand_lik = out->dbg_cand_lik;
         for (int64_t g = 0; g < ng; g++) out->dbg_n_cand[g] = 0;
         B.dbg_n_place = out->dbg_n_place;
+        if (out->dbg_counts && out->dbg_plane_cols > 0) { B.dbg_counts = out->dbg_counts; B.dbg_plane_cols = out->dbg_plane_cols; memset(out->dbg_counts, 0, (size_t)ng * out->dbg_max_cand * out->dbg_plane_cols * 5 * 8); }
+        if (out->dbg_read_maxlv && out->dbg_plane_reads > 0) { B.dbg_read_maxlv = out->dbg_read_maxlv; B.dbg_plane_reads = out->dbg_plane_reads; memset(out->dbg_read_maxlv, 0, (size_t)ng * out->dbg_max_cand * out->dbg_plane_reads * 8); }
     }
     if (out->draw_pos && out->draw_isz && out->draw_len) { B.draw_pos = out->draw_pos; B.draw_isz = out->draw_isz; B.draw_len = out->draw_len; }
     B.n_ureads = (int64_t)K.u_pos.size();

@@ -27,15 +27,73 @@ CASES = {
                         contig_len=8000, neg_overlap_gaps={1: (10, 14)}),
     "edge_contig_ends": dict(seed=41, mode="unmapped", gap_specs=[(25, 20), (3000, 30), (5960, 25)], contig_len=6000, coverage=10, n_model_pairs=800),
     "edge_no_reads": dict(seed=51, mode="partial", gap_specs=[(2000, 40), (4000, 15)], insert_mean=180, insert_sd=10, coverage=0.0, n_model_pairs=800, contig_len=6000),
+    # ---- round 2: reference edge cases of SURVEY §8(c).5 that had no fixture
+    "repeat_flanks": dict(seed=61, mode="partial", gap_specs=[(2000, 30), (4000, 40), (6500, 700)], read_len=100, insert_mean=300, insert_sd=15,
+                          coverage=14, err=0.002, n_model_pairs=600, contig_len=9500),
+    "cap_3001": dict(seed=71, mode="unmapped", gap_specs=[(3000, 25), (6000, 40)], coverage=2400, n_model_pairs=600, max_reads_per_gap=3100),
+    "stat2_hint": dict(seed=81, mode="partial", gap_specs=[(2000, 14), (4000, 18), (6000, 30)], insert_mean=180, insert_sd=10, coverage=24, err=0.003,
+                       n_model_pairs=800, contig_len=8000),
+    "model_indels": dict(seed=91, mode="unmapped", gap_specs=[(3000, 28), (6000, 150)], coverage=10, err=0.01, n_model_pairs=900, model_indel_rate=0.12),
 }
 
 
-def build(name, kw, keep=None):
-    kw = dict(kw)
+def _post_edge_no_reads(case):
+    for g in case.gaps[:1]:
+        g.partial = []
+
+
+def _flank(case, gi, side, n):
+    g = case.gaps[gi]; s = case.scaffolds[0]
+    return s[g.start - n:g.start] if side == "L" else s[g.start + g.length:g.start + g.length + n]
+
+
+def _post_repeat_flanks(case):
+    """findRepeat (Figbird.cpp:1799-1911): a partial read that holds a >=21-bp suffix of the 30-bp left flank twice
+    AND a >=21-bp prefix of the right flank twice is a two-sided repeat (gap 0: skipped in partial mode, :6183-6186);
+    one side only sets one_side_repeat_flag (gap 1: filled with fill=0 semantics; gap 2, > 6 x partial_len long: skipped,
+    :6187-6190).  The reads are crafted: tandem repeats of that size cannot come out of a uniform random genome."""
+    L = case.read_len
+    pad = lambda s: (s + "ACGT" * L)[:L]
+    l0, r0 = _flank(case, 0, "L", 24), _flank(case, 0, "R", 24)
+    g0 = case.gaps[0]
+    two_sided = pad(l0 + l0 + r0 + r0)
+    g0.partial.insert(3, synth.PartialRead(two_sided, 23, 1, g0.start - 23, f"24M{L - 24}S", -1, "I" * L))
+    for gi in (1, 2):
+        g = case.gaps[gi]
+        lf = _flank(case, gi, "L", 26)
+        one = pad(lf + lf + "TTGACCA")
+        g.partial.insert(1, synth.PartialRead(one, 25, 4, g.start - 25, f"26M{L - 26}S", -1, "I" * L))
+
+
+def _post_cap_3001(case):
+    """Preprocess.cpp:1229 lets a gap collect 3001 pairs; Figbird.cpp:7380-7385 then skips it (fillflag=-1)."""
+    case.gaps[0].unmapped = case.gaps[0].unmapped[:3001]
+    assert len(case.gaps[0].unmapped) == 3001
+    case.gaps[1].unmapped = case.gaps[1].unmapped[:36]
+
+
+def _post_stat2_hint(case):
+    """checkMIM's perfect-read hint (Preprocess.cpp:885-925 -> stat2.txt cols 2,3 -> Figbird.cpp:2637): a gap of <= 20 N
+    whose hinted length gets the +300 bonus at exactly that candidate length."""
+    case.gaps[0].stat2 = (1, 1, 9)            # true length 14: the hint pulls the choice to 9
+    case.gaps[1].stat2 = (1, 1, 18)           # hint == true length
+    case.gaps[2].stat2 = (1, 1, 25)           # G0 = 30 > 20: the hint must be ignored
+
+
+POST = {"edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
+
+
+def make(name):
+    """The Case of a golden fixture, exactly as it was generated (tests rebuild in-memory batches from this)."""
+    kw = dict(CASES[name])
     case = synth.make_case(name, kw.pop("seed"), kw.pop("mode"), kw.pop("gap_specs"), **kw)
-    if name == "edge_no_reads":
-        for g in case.gaps[:1]:
-            g.partial = []
+    if name in POST:
+        POST[name](case)
+    return case
+
+
+def build(name, kw=None, keep=None):
+    case = make(name)
     base = tempfile.mkdtemp(prefix="figgold_")
     root = os.path.join(base, name)
     p = synth.write_case(case, root)
@@ -69,7 +127,7 @@ def build(name, kw, keep=None):
 
 
 if __name__ == "__main__":
-    for name, kw in CASES.items():
+    for name in CASES:
         if len(sys.argv) > 1 and name not in sys.argv[1:]:
             continue
-        print(build(name, kw), flush=True)
+        print(build(name), flush=True)
