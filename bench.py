@@ -291,6 +291,7 @@ def main():
     if world > 1:
         import torch.distributed as dist
         dist.destroy_process_group()
+    OUT["fills_run"] = warm_done + warm_more + steps        # fills of the main batch (what a profiler around this command sees)
     OUT["wall_s_total"] = time.perf_counter() - T_PROC0
     emit()
 

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 import util
-from figbird_amd import api, build as fbuild, synth
+from figbird_amd import api, synth
 
 pytestmark = pytest.mark.gpu
 
@@ -34,18 +34,17 @@ def _model_for(root):
                                 read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
 
 
-@pytest.mark.parametrize("name", ["unmapped_small", "unmapped_mid_err", "partial_brackets", "neg_overlap"])
+@pytest.mark.parametrize("name", ["unmapped_small", "unmapped_mid_err", "partial_brackets", "neg_overlap", "repeat_flanks", "cap_3001", "stat2_hint", "model_indels"])
 def test_c_abi_planes_within_tolerance(name, tmp_path):
     """Through the C ABI: filled bases and gaptofill exact; per-candidate likelihood (likelihood_arr,
     Figbird.cpp:6390-6391) within 1e-6 relative of the oracle (device libm vs glibc differ in the last ulp),
     EM iteration counts and valid_count exact."""
-    from tools.make_golden import CASES
+    from tools.make_golden import make
     root = util.extract_golden(name, str(tmp_path))
     tr = str(tmp_path / "o.trace")
     assert util.run_oracle_fillgaps(root, trace=tr).returncode == 0
     oc, _ = util.parse_trace(tr)
-    kw = dict(CASES[name])
-    case = synth.make_case(name, kw.pop("seed"), kw.pop("mode"), kw.pop("gap_specs"), **kw)
+    case = make(name)
     eng = api.Engine(0)
     assert _loaded_native(), "native libfighip.so must be the code that runs"
     eng.set_model(_model_for(root))
@@ -184,23 +183,60 @@ def test_gpu_work_counters_match_oracle(seed, tmp_path):
     assert run_one(mk(seed), str(tmp_path), exe=util.FIGFILL, verbose=False, trace=True)
 
 
+def _oracle_compare(batch, res, sample, mc, spec, tmp_path, timeout=1500):
+    paths = synth.write_batch_subset(batch, sample, mc, str(tmp_path / "cpu"), spec)
+    case_args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
+                 "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
+    r = util.run([util.ORACLE, "fillgaps"] + case_args, str(tmp_path), timeout=timeout)
+    assert r.returncode == 0, r.stderr
+    lines = util.read(paths["tmp"] + "gapout.txt").splitlines()
+    n = 0
+    for k, g in enumerate(paths["gap_order"]):
+        if g not in sample:
+            continue
+        f = lines[k].split("\t")
+        assert int(f[4]) == int(res.filled_len[g]), f"gap {g} (G0={int(batch.gap_len[g])})"
+        assert (f[5] if len(f) > 5 else "") == res.strings[g], f"gap {g} (G0={int(batch.gap_len[g])})"
+        n += 1
+    assert n == len(sample)
+
+
 def test_near_cap_read_counts_match_oracle(tmp_path):
-    """Gaps at the reference's 3000-reads-per-gap cap (Figbird.cpp:5763), one in the 512-thread LDS class and one in the
-    L2-resident-table class (>1216 columns): bytes equal the oracle's."""
+    """Gaps at the reference's 3000-reads-per-gap cap (Figbird.cpp:5763), one in the 512-thread four-row LDS class
+    (<= 1216 columns) and one in the single-row LDS class (1217-1600 columns): bytes equal the oracle's."""
     spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=1.0e6)
     eng, mc = _bench_engine(spec)
     batch, _ = synth.make_bench_batch(99, 2, spec, gap_lengths=np.array([450, 1500]))
     assert int(np.diff(batch.u_read_off).max()) > 2500
     res = eng.fill(batch)
     eng.close()
-    sample = [0, 1]
-    paths = synth.write_batch_subset(batch, sample, mc, str(tmp_path / "cpu"), spec)
-    case_args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
-                 "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
-    r = util.run([util.ORACLE, "fillgaps"] + case_args, str(tmp_path), timeout=900)
-    assert r.returncode == 0, r.stderr
-    lines = util.read(paths["tmp"] + "gapout.txt").splitlines()
-    for k, g in enumerate(paths["gap_order"]):
-        f = lines[k].split("\t")
-        assert int(f[4]) == int(res.filled_len[g]), f"gap {g}"
-        assert (f[5] if len(f) > 5 else "") == res.strings[g], f"gap {g}"
+    _oracle_compare(batch, res, [0, 1], mc, spec, tmp_path)
+
+
+def test_longest_gap_class_matches_oracle(tmp_path):
+    """Gaps whose candidates exceed 1600 columns (fig_pack.h class table: the last class; BASELINE config 5's top bracket,
+    gaps of 1601-2000 bp): 1700 and 2000 bp, plus a 1599/1601 pair either side of the class boundary."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=500.0)
+    eng, mc = _bench_engine(spec)
+    batch, _ = synth.make_bench_batch(2027, 4, spec, gap_lengths=np.array([1700, 2000, 1599, 1601]))
+    res = eng.fill(batch)
+    eng.close()
+    _oracle_compare(batch, res, [0, 1, 2, 3], mc, spec, tmp_path)
+
+
+def test_loguniform_mix_sample_matches_oracle(tmp_path):
+    """BASELINE config 5's gap mix (length log-uniform in [50, 2000]): a seeded batch, a stratified sample of which
+    (one gap per length octave, the cheapest of each for the CPU's sake) is checked against the oracle byte for byte."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=24.0, gap_mix="loguniform")
+    eng, mc = _bench_engine(spec)
+    batch, _ = synth.make_bench_batch(555, 96, spec)
+    res = eng.fill(batch)
+    eng.close()
+    G = np.asarray(batch.gap_len); nr = np.diff(batch.u_read_off)
+    sample = []
+    for lo, hi in [(50, 100), (100, 134), (134, 250), (250, 401), (401, 800), (800, 1217), (1217, 1601), (1601, 2001)]:
+        ids = [g for g in range(batch.n_gaps) if lo <= G[g] < hi]
+        if ids:
+            sample.append(min(ids, key=lambda g: (nr[g] * (G[g] if G[g] <= 400 else 1), g)))
+    assert len(sample) >= 7
+    _oracle_compare(batch, res, sample, mc, spec, tmp_path, timeout=2400)

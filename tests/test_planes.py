@@ -36,13 +36,12 @@ def _close(a, b, tol):
 
 
 def check_planes(lib_path, name, tmp_path, tol):
-    from tools.make_golden import CASES
+    from tools.make_golden import make
     root = util.extract_golden(name, str(tmp_path))
     tr = str(tmp_path / "o.trace")
     assert util.run_oracle_fillgaps(root, trace=tr, level=3).returncode == 0
     planes = parse_planes(tr)
-    kw = dict(CASES[name])
-    case = synth.make_case(name, kw.pop("seed"), kw.pop("mode"), kw.pop("gap_specs"), **kw)
+    case = make(name)
     a = util.meta(root)["fillgaps_argv"]
     model = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
                                  partial_flag=int(a[4]), unmapped_flag=int(a[5]), script_itr=int(a[3]), max_distance=int(a[1]),

@@ -16,7 +16,7 @@ def model_for(spec, seed=7):
 
 if __name__ == "__main__":
     mode = sys.argv[1]
-    lens = [int(x) for x in sys.argv[2].split(",")]
+    lens = [int(x) if x != "mix" else -1 for x in sys.argv[2].split(",")]     # "mix": the default bench batch (GAGE gap mix, bench seed)
     reps = int(sys.argv[3])
     rpg = float(sys.argv[4]) if len(sys.argv) > 4 else 1000.0
     spec = synth.BenchSpec(mode=mode) if mode == "unmapped" else synth.BenchSpec(mode="partial", read_len=101, insert_mean=180, insert_sd=10)
@@ -26,8 +26,8 @@ if __name__ == "__main__":
     eng = api.Engine(0, lib_path=os.environ.get("FIG_LIB"))
     eng.set_model(m)
     for G in lens:
-        gl = np.full(reps, G)
-        t0 = time.time(); batch, truth = synth.make_bench_batch(11 + G, reps, spec, gap_lengths=gl); tg = time.time() - t0
+        gl = np.full(reps, G) if G > 0 else None
+        t0 = time.time(); batch, truth = synth.make_bench_batch(11 + G if G > 0 else 20260101, reps, spec, gap_lengths=gl); tg = time.time() - t0
         nr = int(batch.u_read_off[-1]) if mode == "unmapped" else int(batch.p_read_off[-1])
         t0 = time.time(); eng.upload(batch); tu = time.time() - t0
         t0 = time.time(); res = eng.fill_resident(); tf = time.time() - t0

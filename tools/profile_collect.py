@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 runs of tools/profile_bench.sh into small, committable summaries:
+  <out>/summary/<tag>_kernel_stats.csv   per-kernel calls / total / average duration (the --stats table)
+  <out>/summary/<tag>_pmc_<COUNTER>.csv  per-kernel counter sums
+  <out>/summary/<tag>_traffic.json       HBM bytes per fill from FETCH_SIZE (x2: gfx950 wide-read correction of the
+                                         microarch guide) + WRITE_SIZE, with the bench lines of the counter runs
+ROCm 7.2's rocprofv3 writes a rocpd sqlite database per run (tools/rocpd_summary.py reads its views)."""
+import csv, glob, json, os, sqlite3, subprocess, sys
+
+
+def db_of(d):
+    c = sorted(glob.glob(os.path.join(d, "**", "*.db"), recursive=True))
+    return c[0] if c else None
+
+
+def last_json(path):
+    try:
+        lines = [l for l in open(path).read().splitlines() if l.startswith("{")]
+        return json.loads(lines[-1]) if lines else None
+    except Exception:
+        return None
+
+
+def counter_sum(db, name):
+    con = sqlite3.connect(db)
+    rows = list(con.execute("select kernel_name, count(*), sum(value) from counters_collection where counter_name=? group by kernel_name", (name,)))
+    return rows
+
+
+def main():
+    out, tag = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    sm = os.path.join(out, "summary"); os.makedirs(sm, exist_ok=True)
+    d = db_of(os.path.join(out, "stats"))
+    if d:
+        subprocess.run([sys.executable, os.path.join(here, "rocpd_summary.py"), "stats", d, os.path.join(sm, f"{tag}_kernel_stats.csv")], check=False)
+    traffic = {}
+    for cname, key, sub in (("FETCH_SIZE", "fetch", "pmc_fetch"), ("WRITE_SIZE", "write", "pmc_write")):
+        d = db_of(os.path.join(out, sub))
+        line = last_json(os.path.join(out, f"bench_{sub}.json"))
+        if not d or not line:
+            continue
+        subprocess.run([sys.executable, os.path.join(here, "rocpd_summary.py"), "pmc", d, os.path.join(sm, f"{tag}_pmc_{cname}.csv")], check=False)
+        rows = [r for r in counter_sum(d, cname) if "fig_" in r[0]]
+        fills = int(line.get("fills_run", line.get("steps", 1) + line.get("warmup", 0)))
+        kb = sum(r[2] for r in rows)                       # rocprofv3 reports FETCH_SIZE / WRITE_SIZE in KB
+        traffic[key] = {"counter_kb_total": kb, "fills": fills, "bytes_per_fill_raw": kb * 1024.0 / max(fills, 1), "bench_line": {k: line.get(k) for k in ("value", "steps", "warmup", "ms_per_step")}}
+    d = db_of(os.path.join(out, "pmc_sq"))
+    if d:
+        subprocess.run([sys.executable, os.path.join(here, "rocpd_summary.py"), "pmc", d, os.path.join(sm, f"{tag}_pmc_SQ.csv")], check=False)
+    if "fetch" in traffic and "write" in traffic:
+        traffic["bytes_per_step"] = 2.0 * traffic["fetch"]["bytes_per_fill_raw"] + traffic["write"]["bytes_per_fill_raw"]
+        traffic["note"] = "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 reports half the bytes of wide reads; upper bound for the dword scratch share) + --pmc WRITE_SIZE, fig_* kernels, per fill"
+    json.dump(traffic, open(os.path.join(sm, f"{tag}_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic))
+
+
+if __name__ == "__main__":
+    main()
