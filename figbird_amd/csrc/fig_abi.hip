@@ -26,7 +26,8 @@
 #ifdef FIG_PROF
 #define FIG_PROF_BEGIN() const unsigned long long _k0 = __builtin_readcyclecounter()
 #define FIG_PROF_FLUSH() do { if (E.lane == 0) { atomicAdd(&B.counters[30], E.wait_cycles); atomicAdd(&B.counters[31], (unsigned long long)__builtin_readcyclecounter() - _k0); \
-    for (int i = 0; i < 22; i++) if (E.prof[i]) atomicAdd(&B.counters[8 + i], E.prof[i]); } } while (0)
+    for (int i = 0; i < 22; i++) if (E.prof[i]) atomicAdd(&B.counters[8 + i], E.prof[i]); \
+    for (int i = 22; i < 40; i++) if (E.prof[i]) atomicAdd(&B.counters[32 + (i - 22)], E.prof[i]); } } while (0)
 #else
 #define FIG_PROF_BEGIN() ((void)0)
 #define FIG_PROF_FLUSH() ((void)0)
@@ -40,7 +41,7 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.lane = threadIdx.x & 63; E.wave = threadIdx.x >> 6; E.nw = (blockDim.x + 63) >> 6; E.wsz = 64;
     E.M = &M; E.B = &B;
     E.capG = A.capG; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0;
-    for (int i = 0; i < 22; i++) E.prof[i] = 0;
+    for (int i = 0; i < 40; i++) E.prof[i] = 0;
     E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
     fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &work);
@@ -425,7 +426,7 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)str_total, &p))) return rc; db.str = (char *)p;
     if ((rc = dev_alloc(ctx, 64 * (ctx->classes.size() + 1), &p))) return rc; db.queue_head = (int32_t *)p;
-    if ((rc = dev_alloc(ctx, 256, &p))) return rc; db.counters = (unsigned long long *)p;
+    if ((rc = dev_alloc(ctx, 512, &p))) return rc; db.counters = (unsigned long long *)p;
     size_t total_blocks = 0;
     for (const fig_ctx::Cls &c : ctx->classes) total_blocks += (size_t)c.capacity;
     (void)max_blocks;
@@ -452,7 +453,7 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     db.scratch_stride = stride;
     db.capG = capG_s; db.capR = capR; db.capP = capP; db.capC = capC; db.capW = K.capW; db.capE = K.capE;
     db.n_ureads = ctx->n_ureads;
-    FIG_HIP(hipMemsetAsync(db.counters, 0, 256, ctx->stream));
+    FIG_HIP(hipMemsetAsync(db.counters, 0, 512, ctx->stream));
     FIG_HIP(hipMemsetAsync(db.queue_head, 0, 64 * (ctx->classes.size() + 1), ctx->stream));
     hipEventRecord(ctx->ev1, ctx->stream);
     FIG_HIP(hipStreamSynchronize(ctx->stream));
@@ -627,7 +628,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         if (talloc((size_t)ng * 8, &p)) { tfree(); return FIG_ENOMEM; } db.draw_len = (int32_t *)p;
         hipMemsetAsync(db.draw_isz, 0, (size_t)nr * 4, ctx->stream);
     }
-    hipMemsetAsync(db.counters, 0, 256, ctx->stream);
+    hipMemsetAsync(db.counters, 0, 512, ctx->stream);
     // a previous call that failed half-way may have left queue heads / ping-pong selectors inconsistent: start clean
     hipMemsetAsync(db.queue_head, 0, 64 * (ctx->classes.size() + 1), ctx->stream);
     for (auto &l : ctx->lanes) l.qsel = 0;
@@ -679,8 +680,8 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     hipMemcpyAsync(out->filled_len, db.filled_len, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
     hipMemcpyAsync(out->gaptofill, db.gaptofill, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
     if (ctx->str_total) hipMemcpyAsync(hstr.data(), db.str, (size_t)ctx->str_total, hipMemcpyDeviceToHost, ctx->stream);
-    unsigned long long cnt[32] = {0};
-    hipMemcpyAsync(cnt, db.counters, 256, hipMemcpyDeviceToHost, ctx->stream);
+    unsigned long long cnt[64] = {0};
+    hipMemcpyAsync(cnt, db.counters, 512, hipMemcpyDeviceToHost, ctx->stream);
     if (db.dbg_n_cand) {
         hipMemcpyAsync(out->dbg_n_cand, db.dbg_n_cand, (size_t)ng * 4, hipMemcpyDeviceToHost, ctx->stream);
         hipMemcpyAsync(out->dbg_cand_i, db.dbg_cand_i, (size_t)ng * out->dbg_max_cand * 12, hipMemcpyDeviceToHost, ctx->stream);
@@ -705,7 +706,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
       for (int i = 0; i < 14; i++) fprintf(stderr, "[figprof] %-9s %8.1f Gcycles = %5.1f %% of wave-cycles\n", nm[i], cnt[8 + i] / 1e9, cnt[31] ? 100.0 * cnt[8 + i] / cnt[31] : 0.0);
       { const char *mn[4] = {"M.setup", "M.hint", "M.rounds", "M.surv"};
         for (int i = 0; i < 4; i++) fprintf(stderr, "[figprof] %-9s %8.1f Gcycles = %5.1f %% of wave-cycles\n", mn[i], cnt[22 + i] / 1e9, cnt[31] ? 100.0 * cnt[22 + i] / cnt[31] : 0.0); }
-      fprintf(stderr, "[figprof] raw slots:"); for (int i = 0; i < 22; i++) fprintf(stderr, " %d:%.1f", i, cnt[8 + i] / 1e9); fprintf(stderr, "\n");
+      fprintf(stderr, "[figprof] raw slots:"); for (int i = 0; i < 22; i++) fprintf(stderr, " %d:%.1f", i, cnt[8 + i] / 1e9); for (int i = 22; i < 40; i++) fprintf(stderr, " %d:%.1f", i, cnt[32 + i - 22] / 1e9); fprintf(stderr, "\n");
       fprintf(stderr, "[figprof] barrier wait %.3f of %.3f wave-Gcycles = %.1f %%\n", cnt[30] / 1e9, cnt[31] / 1e9, cnt[31] ? 100.0 * cnt[30] / cnt[31] : 0.0); }
 #endif
     if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] useful flops %.4g, speculative evaluations executed %.4g (%.1f %% discarded)\n", (double)cnt[1], (double)cnt[2], cnt[2] ? 100.0 * (1.0 - ((double)cnt[1] / (double)cnt[2])) : 0.0);

@@ -163,6 +163,7 @@ struct FigScr {
     int *pc;           // partial_count_array [4][capG]
     int *nci;          // integer pile-up of accepted reads [5][capG] (new_counts_gap / finalize's countsGap increments)
     unsigned char *accf; // [R] accepted flag of the current MLE pass
+    unsigned char *mdone; // [R] the lane-per-read MLE path finished this read's search (fig_hot_mle)
     int *cov;          // gap_coverage [capG]
     int *region;       // [capG+8]
     unsigned char *cons, *best, *cur, *prev, *orig;   // strings [capG+1]
@@ -175,6 +176,8 @@ struct FigScr {
     int *fin;          // finalize's unmapped_read_pos_arr [R][2]
     FigTrip *sortbuf;  // [R]
     int *hint;         // [R] best placement of the previous MLE pass over this read (pruning hint only; never affects results)
+    int *hint_e;       // [R] arg-max placement of the last E-step over this read (second pruning hint)
+    double *hval;      // [R] MLE product at the chosen hint, evaluated lane-per-read before the per-read loop (-1: not evaluated)
     // per partial read
     int *repeatflag;   // [P][3]
     int *ppos_org;     // partial_read_pos_arr_org [P][3]
@@ -201,6 +204,7 @@ FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int
     FIG_CARVE(q4g, double, capE);
     FIG_CARVE(wg, double, capW);
     FIG_CARVE(maxlv, double, capR > capP ? capR : capP);
+    FIG_CARVE(hval, double, capR);
     FIG_CARVE(pc, int, 4LL * capG);
     FIG_CARVE(nci, int, 5LL * capG);
     FIG_CARVE(cov, int, capG);
@@ -210,6 +214,7 @@ FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int
     FIG_CARVE(fin, int, 2LL * capR);
     FIG_CARVE(sortbuf, FigTrip, capR);
     FIG_CARVE(hint, int, capR);
+    FIG_CARVE(hint_e, int, capR);
     FIG_CARVE(repeatflag, int, 3LL * capP);
     FIG_CARVE(ppos_org, int, 3LL * capP);
     FIG_CARVE(pflag, int, 2LL * capP);
@@ -227,6 +232,7 @@ FIG_HD long long fig_scratch_layout(unsigned char *base, int capG, int capR, int
     FIG_CARVE(mark, unsigned char, capR + 8);
     FIG_CARVE(saved, unsigned char, capR + 8);
     FIG_CARVE(accf, unsigned char, capR + 8);
+    FIG_CARVE(mdone, unsigned char, capR + 8);
     FIG_CARVE(smflag, unsigned char, capP + 8);
 #undef FIG_CARVE
     return o;
@@ -261,7 +267,7 @@ struct FigEng {
     unsigned long long mle_alg;      // per-lane share of `flops` credited to the MLE passes (1 per placement and base)
     unsigned long long mle_exec;     // FP64 multiplies the MLE passes actually executed after pruning (wave total, kept in lane 0)
     unsigned long long wait_cycles;  // FIG_PROF only: cycles spent in workgroup barriers
-    unsigned long long prof[22];     // FIG_PROF only: phase timers
+    unsigned long long prof[40];     // FIG_PROF only: phase timers
 };
 
 // ---------------------------------------------------------------------------------------

@@ -272,7 +272,7 @@ FIG_D int fig_initialize(FigEng &E, int gl, int negGapCheck) {
     }
     int nml = E.g->nU > E.g->nP ? E.g->nU : E.g->nP;
     for (int r = E.tid; r < nml; r += E.nt) E.scr.maxlv[r] = 0;
-    for (int r = E.tid; r < E.g->nU; r += E.nt) E.scr.hint[r] = FIG_NOPOS;
+    for (int r = E.tid; r < E.g->nU; r += E.nt) { E.scr.hint[r] = FIG_NOPOS; E.scr.hint_e[r] = FIG_NOPOS; }
     FIG_SYNC();
     if (E.tid == 0) {
         int gfp = 0;

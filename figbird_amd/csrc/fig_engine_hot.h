@@ -100,6 +100,15 @@ FIG_D double fig_wave_max_dpp(double v) {
 #endif
 }
 
+FIG_D int fig_ctz64(unsigned long long m) { return __builtin_ctzll(m); }   // m != 0
+FIG_D int fig_lane_read_i32(int v, int lane) {      // value of `v` in lane `lane` (wave-uniform index)
+#ifdef FIG_EMU
+    (void)lane;
+    return v;
+#else
+    return __builtin_amdgcn_readlane(v, __builtin_amdgcn_readfirstlane(lane));
+#endif
+}
 FIG_D unsigned long long fig_ballot(bool p) {
 #ifdef FIG_EMU
     return p ? 1ULL : 0ULL;
@@ -407,6 +416,7 @@ FIG_D void fig_build_mle_table(FigEng &E, int G, int left, int right) {
 }
 
 struct FigReadS { int len, rev, hasN, pos; long long woff; };
+struct alignas(16) FigU4 { uint32_t x, y, z, w; };      // one ds_read_b128
 
 struct FigHotU {                     // wave-uniform copies of what the hot loops need
     const int32_t *u_len, *u_aux, *u_pos; const int64_t *u_woff; const uint32_t *packed; const double *insd;
@@ -496,6 +506,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
         int r = c0 + team;
         FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
         if (team < nteams && r < nU) {
+            FIG_T0(E);
             FigReadS rs = fig_read_scalars(U, ub + r);
             FigWin w = fig_window_u(U, rs.pos, rs.len, gapoffset);
             if (wit == 0 && lane == 0) { S.tm_lo[team] = w.lo; S.tm_hi[team] = w.hi; S.tm_len[team] = rs.len; }
@@ -525,6 +536,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 // otherwise sit in front of the first multiply)
                 double pa_n = 0, pb_n = 0;
                 if (nfull > 0) { const int oa0 = w.lo + wit * U.wsz + lane; pa_n = U.insd[w.tis0 + w.dir * oa0]; pb_n = U.insd[w.tis0 + w.dir * (oa0 + stride)]; }
+                FIG_TICK(E, 22);
                 for (int k = 0; k < nfull; k++) {
 #ifndef FIG_EMU
                     // 8-wave workgroups put waves w and w+4 on one SIMD and the arbiter serves the older one first; taking
@@ -583,14 +595,17 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                         const bool va = lane < m;
                         const int ca = va ? oa : start;
                         double pa = U.insd[w.tis0 + w.dir * ca];
+                        FIG_T0(E);
                         fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
                         const double ta = fig_log10(pa);
                         const double wa = fig_exp(0.5 * ta);
                         if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; nadd += fig_ovl(oa, rs.len, G); }
+                        FIG_TICK(E, 23);
                     }
                 }
                 o = w.hi + 1;
             }
+            { FIG_T0(E);
             for (; o <= w.hi; o += stride) {
                 int tis = w.tis0 + w.dir * o;
                 int jstart = clipped ? (-left - o > 0 ? -left - o : 0) : 0;
@@ -600,10 +615,14 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
                 wrow[o] = fig_exp(0.5 * t);
                 nplace++; nadd += fig_ovl(o, rs.len, G);
             }
+            FIG_TICK(E, 24); }
             fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
-            // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do
+            // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do; the
+            // offset of (one of) the maximal placements is kept as a pruning hint for the MLE pass of this placeReads call
             { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
-              if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? 0 : FIG_NOPOS; } }
+              const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
+              const int ao = am ? fig_lane_read_i32(best.o, fig_ctz64(am)) : FIG_NOPOS;
+              if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; } }
             if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;
         }
         FIG_TICK(E, 11);
@@ -615,6 +634,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
             for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[tid * T + k]; y.o = S.wv_o[tid * T + k]; b = fig_best_merge(b, y); }
             if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + tid] = b.v;
             else { E.scr.maxlv[c0 + tid] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
+            E.scr.hint_e[c0 + tid] = b.o;
         }
         // ---- phase B: lanes = gap columns; reads of the chunk in order.  For one read the additions into the
         // five per-base accumulators of a column are independent chains; each chain walks that base's positions
@@ -855,6 +875,22 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             kc[wd] = c2; kn[wd] = n2;
         }
     }
+    // 32-column windows of the packed consensus, one 16-byte record per column {codes lo, codes hi, N lo, N hi}, in the part
+    // of the table area the MLE table leaves free (C uses 5 of the 9 doubles per column): the sweep below then needs ONE
+    // ds_read_b128 per placement instead of six word reads and four funnel shifts
+    const bool use_cw = LDS && use_kf;
+    FigU4 *cwn = (FigU4 *)(fig_lds + fig_u(E.off_pq) + 5LL * ncolE);
+    if (use_cw) {
+        FIG_SYNC();                                   // kc / kn complete
+        for (int i = E.tid; i < ncolE; i += E.nt) {
+            const int wi = i >> 4, sh = (i & 15) * 2;
+            const uint32_t a0 = kc[wi], a1 = kc[wi + 1], a2 = kc[wi + 2], b0 = kn[wi], b1 = kn[wi + 1], b2 = kn[wi + 2];
+            FigU4 v;
+            v.x = sh ? (a0 >> sh) | (a1 << (32 - sh)) : a0; v.y = sh ? (a1 >> sh) | (a2 << (32 - sh)) : a1;
+            v.z = sh ? (b0 >> sh) | (b1 << (32 - sh)) : b0; v.w = sh ? (b1 >> sh) | (b2 << (32 - sh)) : b1;
+            cwn[i] = v;
+        }
+    }
     fig_build_mle_table(E, gl, wl, wr);             // ends with a barrier
     const double *C = fig_c_ptr<LDS>(E);
     const double init = mode == 0 ? -FIG_DBL_MAX : 0.0;
@@ -864,12 +900,127 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     double *fbuf = fig_w_ptr<LDS>(E) + (use_serial ? wave * FIG_MLE_FB : 0);
     FIG_T0(E);
     (void)nteams; (void)team;
+    // ---- Lane-per-read path.  For reads of full length without N (nearly all of them) the whole search runs with ONE READ
+    // PER LANE, 64 reads side by side, so that nothing in it waits on a wave-uniform dependency chain:
+    //   (1) hints: the MLE product at the previous pass's best placement and at the E-step's arg-max (same factors, same
+    //       order as fig_mle_serial / the chains: same bits); the better one is the read's running maximum `bound`;
+    //   (2) sweep: every placement of the window is judged by the mismatches of its first 32 bases against the packed
+    //       consensus (one 16-byte record per placement); a placement with m mismatches has a product <= fmm^m, so only
+    //       those with m < mcut(bound) can reach the maximum; the few that pass get the whole-read count, and those that
+    //       pass that too (at most two per read, else the read is left to the wave-per-read loop below) are
+    //   (3) evaluated, again lane-parallel, and merged "first maximum wins";
+    //   (4) the accept test, flags and integer pile-up of these reads follow after the wave-per-read loop (same order-free
+    //       integer / flag updates as there).
+    // Value and arg-max are exactly those of the full scan: every placement that could reach or tie the hint's product
+    // passes both filters.
+    unsigned char *mdone = E.scr.mdone;
+    const bool lane_path = use_cw && mono;
+    {
+        fig_cdp mtf = (fig_cdp)U.mt_fwd, mtr = (fig_cdp)U.mt_rev;
+        const int Lfull = U.L;
+        const int nw2f = (Lfull + 15) >> 4;
+        for (int r0 = 0; r0 < nU; r0 += U.nt) {
+            const int r = r0 + E.tid;
+            bool part = false;
+            int h1 = FIG_NOPOS, h2 = FIG_NOPOS, rev = 0;
+            const uint32_t *pkl = U.packed;
+            FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
+            if (r < nU) {
+                const int len = U.u_len[ub + r], aux = U.u_aux[ub + r];
+                rev = aux & 1;
+                mdone[r] = 0;
+                E.scr.hval[r] = -1.0;
+                if (len == Lfull && !((aux >> 1) & 1)) {
+                    w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
+                    h1 = E.scr.hint[r]; h2 = E.scr.hint_e[r];
+                    if (h1 != FIG_NOPOS && (h1 < w.lo || h1 > w.hi)) h1 = FIG_NOPOS;
+                    if (h2 != FIG_NOPOS && (h2 < w.lo || h2 > w.hi || h2 == h1)) h2 = FIG_NOPOS;
+                    if (h1 == FIG_NOPOS) { h1 = h2; h2 = FIG_NOPOS; }
+                    part = h1 != FIG_NOPOS;
+                    pkl = U.packed + U.u_woff[ub + r];
+                }
+            }
+            if (!fig_wave_any(part)) continue;
+            // (1) + (3): up to two candidate placements per lane, one dependent multiply chain each
+            FigBest a; a.v = init; a.o = FIG_NOPOS;
+            int c1 = h1, c2 = h2;
+            bool sw = false, ovf = false; int mcut = 0;
+            for (int pass = 0; pass < 2; pass++) {
+                const bool ev = part && c1 != FIG_NOPOS;
+                if (fig_wave_any(ev)) {
+                    const bool two = fig_wave_any(ev && c2 != FIG_NOPOS);
+                    const int xa = (ev ? c1 : 0) + xoff, xb = (ev && c2 != FIG_NOPOS ? c2 : (ev ? c1 : 0)) + xoff;
+                    double qa = 1, qb = 1;
+                    for (int wi = 0; wi < nw2f; wi++) {
+                        const uint32_t wd = ev ? pkl[wi] : 0u;
+                        const int j0 = wi * 16;
+                        int nb = Lfull - j0; if (nb > 16) nb = 16;
+                        for (int jj = 0; jj < nb; jj++) {
+                            const int j = j0 + jj;
+                            const int b = (int)((wd >> (2 * jj)) & 3);
+                            const double m3 = rev ? mtr[2 * j] : mtf[2 * j], e = rev ? mtr[2 * j + 1] : mtf[2 * j + 1];
+                            const double ca = C[b * ncolE + xa + j];
+                            const double fa = e * ca;
+                            qa *= (ca < 0 ? m3 : fa);
+                            if (two) {
+                                const double cb = C[b * ncolE + xb + j];
+                                const double fb = e * cb;
+                                qb *= (cb < 0 ? m3 : fb);
+                            }
+                        }
+                    }
+                    ex_acc += (unsigned long long)Lfull * (unsigned long long)(fig_popc64(fig_ballot(ev)) + fig_popc64(fig_ballot(ev && c2 != FIG_NOPOS)));
+                    if (ev) {
+                        if (qa > init) { FigBest y; y.v = qa; y.o = c1; a = fig_best_merge(a, y); }
+                        if (c2 != FIG_NOPOS && qb > init) { FigBest y; y.v = qb; y.o = c2; a = fig_best_merge(a, y); }
+                    }
+                }
+                if (pass == 1) break;
+                // (2) the sweep, for lanes whose hint gives a sharp cut
+                sw = lane_path && part && a.o != FIG_NOPOS && a.v > 1e-290 && Lfull >= 32;
+                if (sw) { mcut = (int)(fig_log(a.v) / lfmm) + 2; sw = mcut <= 18; }
+                c1 = c2 = FIG_NOPOS;
+                if (!fig_wave_any(sw)) break;
+                const uint32_t rw0 = sw ? pkl[0] : 0u, rw1 = sw ? pkl[1] : 0u;
+                const int Wn = sw ? w.hi - w.lo + 1 : 0;
+                const FigU4 *cwx = cwn + xoff;
+                for (int i = 0; fig_wave_any(i < Wn); i++) {
+                    if (i >= Wn) continue;
+                    const int o = w.lo + i;
+                    const FigU4 rec = cwx[o];
+                    const uint32_t d0 = rec.x ^ rw0, d1 = rec.y ^ rw1;
+                    const int mm = __builtin_popcount(((d0 | (d0 >> 1)) | rec.z) & 0x55555555u) + __builtin_popcount(((d1 | (d1 >> 1)) | rec.w) & 0x55555555u);
+                    if (mm < mcut && o != h1 && o != h2) {
+                        int mmf = 0;                                  // whole-read count, 32 bases per record
+                        for (int k = 0; 32 * k < Lfull; k++) {
+                            const FigU4 rk = cwx[o + 32 * k];
+                            const int nbk = Lfull - 32 * k;
+                            const uint32_t mlo = nbk >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - nbk)));
+                            const uint32_t mhi = nbk >= 32 ? 0x55555555u : (nbk > 16 ? (0x55555555u >> (2 * (32 - nbk))) : 0u);
+                            const uint32_t e0 = rk.x ^ pkl[2 * k], e1 = rk.y ^ pkl[2 * k + 1];
+                            mmf += __builtin_popcount(((e0 | (e0 >> 1)) | rk.z) & mlo) + __builtin_popcount(((e1 | (e1 >> 1)) | rk.w) & mhi);
+                        }
+                        if (mmf < mcut) { if (c1 == FIG_NOPOS) c1 = o; else if (c2 == FIG_NOPOS) c2 = o; else ovf = true; }
+                    }
+                }
+            }
+            if (part) {
+                E.scr.hint[r] = a.o;
+                if (sw && !ovf) { E.scr.hval[r] = a.v; mdone[r] = 1; fl_acc += (unsigned long long)(w.hi - w.lo + 1) * (unsigned long long)Lfull; }
+                else if (!sw && a.o != FIG_NOPOS) E.scr.hval[r] = a.v;     // the wave-per-read loop starts from this maximum
+                // (sw && ovf: too many survivors for two slots; hval stays -1 and the loop below redoes the read in full)
+            }
+        }
+        FIG_SYNC();
+    }
+    FIG_TICK(E, 18);
     while (true) {
         // waves take reads dynamically (reads differ a lot in cost once pruning works), so the pass ends evenly
         int r = 0;
         if (lane == 0) r = fig_atomic_fetch_add_i32(&S.mle_next, 1);
         r = fig_u(r);
         if (r >= nU) break;
+        if (mdone[r]) continue;                          // finished by the lane-per-read path; accepted after this loop
         const bool active = true;
         FigReadS rs; rs.len = 0; rs.rev = 0; rs.hasN = 0; rs.pos = 0; rs.woff = 0;
         FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
@@ -907,7 +1058,8 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 if (h != FIG_NOPOS && h >= obase && h <= w.hi) {
                     r0 = (h - obase) / (2 * stride); if (r0 >= nrounds) r0 = 0;
                     if (use_serial) {
-                        ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, h + xoff, fbuf, lane, U.wsz);
+                        double v = fig_bcast_d(E.scr.hval[r]);          // evaluated lane-per-read above (full-length reads)
+                        if (v < 0) { ex_acc += (unsigned long long)rs.len; v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, h + xoff, fbuf, lane, U.wsz); }
                         if (v > init) { ub.v = v; ub.o = h; bound = v; }
                     }
                 }
@@ -926,50 +1078,70 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     const uint32_t rwl = pk[lwq];
                     const int reml = rs.len - lwq * 16;
                     const uint32_t lml = lane < nwr ? (reml >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - reml)))) : 0u;
-                    for (int ob0 = w.lo; ob0 <= w.hi; ob0 += U.wsz) {
-                        const int o1 = ob0 + lane;
-                        const bool ok1 = o1 <= w.hi;
-                        if (ok1) nplace++;
-                        const int xe = (ok1 ? o1 : w.hi) + xoff;
-                        const int wi = xe >> 4, sh = (xe & 15) * 2;
-                        const uint32_t c0 = kc[wi], c1 = kc[wi + 1], c2 = kc[wi + 2], n0 = kn[wi], n1 = kn[wi + 1], n2 = kn[wi + 2];
-                        const uint32_t cv0 = sh ? (c0 >> sh) | (c1 << (32 - sh)) : c0, nv0 = sh ? (n0 >> sh) | (n1 << (32 - sh)) : n0;
-                        const uint32_t cv1 = sh ? (c1 >> sh) | (c2 << (32 - sh)) : c1, nv1 = sh ? (n1 >> sh) | (n2 << (32 - sh)) : n1;
-                        const uint32_t d0 = cv0 ^ rw0, d1 = cv1 ^ rw1;
-                        const int mm = __builtin_popcount(((d0 | (d0 >> 1)) | nv0) & 0x55555555u) + __builtin_popcount(((d1 | (d1 >> 1)) | nv1) & 0x55555555u);
-                        if (bound != mcut_for) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
-                        unsigned long long cm = fig_ballot(ok1 && mm < mcut_cur);
-                        while (cm) {
-                            int bit = 0; { unsigned long long t = cm; while (!(t & 1)) { t >>= 1; bit++; } }
-                            cm &= cm - 1;
-                            const int os = ob0 + bit;
-                            if (os == ub.o) continue;                             // the hint, already evaluated
-                            // whole-read mismatch count of placement os: lane q handles word q, then a sum over the lanes
-                            const int xs = os + xoff + lwq * 16;
-                            const int wj = xs >> 4, sj = (xs & 15) * 2;
-                            const uint32_t e0 = kc[wj], e1 = kc[wj + 1], f0 = kn[wj], f1 = kn[wj + 1];
-                            const uint32_t ev = sj ? (e0 >> sj) | (e1 << (32 - sj)) : e0, fv = sj ? (f0 >> sj) | (f1 << (32 - sj)) : f0;
-                            const uint32_t dd = ev ^ rwl;
-                            int mml = __builtin_popcount(((dd | (dd >> 1)) | fv) & lml);
-                            int mmf = 0;
-#ifdef FIG_EMU
-                            mmf = 0;
-                            for (int q2 = 0; q2 < nwr; q2++) {
-                                const int xq = os + xoff + q2 * 16; const int wq2 = xq >> 4, sq2 = (xq & 15) * 2;
-                                const uint32_t g0 = kc[wq2], g1 = kc[wq2 + 1], h0 = kn[wq2], h1 = kn[wq2 + 1];
-                                const uint32_t gv = sq2 ? (g0 >> sq2) | (g1 << (32 - sq2)) : g0, hv = sq2 ? (h0 >> sq2) | (h1 << (32 - sq2)) : h0;
-                                const uint32_t dq = gv ^ pk[q2]; const int remq = rs.len - q2 * 16;
-                                const uint32_t lq = remq >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - remq)));
-                                mmf += __builtin_popcount(((dq | (dq >> 1)) | hv) & lq);
+                    // four 64-placement groups per trip: their records are fetched together (one LDS latency per trip) and
+                    // nearly every trip ends at the combined ballot
+                    for (int ob0 = w.lo; ob0 <= w.hi; ob0 += 4 * U.wsz) {
+                        unsigned long long cm4[4];
+                        FigU4 rec4[4]; bool ok4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int o1 = ob0 + k * U.wsz + lane;
+                            ok4[k] = o1 <= w.hi;
+                            const int xe = (ok4[k] ? o1 : w.hi) + xoff;
+                            if (use_cw) rec4[k] = cwn[xe];
+                            else {
+                                const int wi = xe >> 4, sh = (xe & 15) * 2;
+                                const uint32_t c0 = kc[wi], c1 = kc[wi + 1], c2 = kc[wi + 2], n0 = kn[wi], n1 = kn[wi + 1], n2 = kn[wi + 2];
+                                rec4[k].x = sh ? (c0 >> sh) | (c1 << (32 - sh)) : c0; rec4[k].z = sh ? (n0 >> sh) | (n1 << (32 - sh)) : n0;
+                                rec4[k].y = sh ? (c1 >> sh) | (c2 << (32 - sh)) : c1; rec4[k].w = sh ? (n1 >> sh) | (n2 << (32 - sh)) : n1;
                             }
-                            (void)mml;
+                        }
+                        if (bound != mcut_for) { mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (ok4[k]) nplace++;
+                            const uint32_t d0 = rec4[k].x ^ rw0, d1 = rec4[k].y ^ rw1;
+                            const int mm = __builtin_popcount(((d0 | (d0 >> 1)) | rec4[k].z) & 0x55555555u) + __builtin_popcount(((d1 | (d1 >> 1)) | rec4[k].w) & 0x55555555u);
+                            cm4[k] = fig_ballot(ok4[k] && mm < mcut_cur);
+                        }
+                        FIG_COUNT(E, 19, lane == 0 ? 1 : 0);
+                        if (!(cm4[0] | cm4[1] | cm4[2] | cm4[3])) continue;
+                        for (int k = 0; k < 4; k++) {
+                            unsigned long long cm = cm4[k];
+                            while (cm) {
+                                const int bit = fig_ctz64(cm);
+                                cm &= cm - 1;
+                                const int os = ob0 + k * U.wsz + bit;
+                                if (os == ub.o) continue;                             // the hint, already evaluated
+                                FIG_COUNT(E, 20, lane == 0 ? 1 : 0);
+                                // whole-read mismatch count of placement os: lane q handles word q, then a sum over the lanes
+                                const int xs = os + xoff + lwq * 16;
+                                const int wj = xs >> 4, sj = (xs & 15) * 2;
+                                const uint32_t e0 = kc[wj], e1 = kc[wj + 1], f0 = kn[wj], f1 = kn[wj + 1];
+                                const uint32_t ev = sj ? (e0 >> sj) | (e1 << (32 - sj)) : e0, fv = sj ? (f0 >> sj) | (f1 << (32 - sj)) : f0;
+                                const uint32_t dd = ev ^ rwl;
+                                int mml = __builtin_popcount(((dd | (dd >> 1)) | fv) & lml);
+                                int mmf = 0;
+#ifdef FIG_EMU
+                                mmf = 0;
+                                for (int q2 = 0; q2 < nwr; q2++) {
+                                    const int xq = os + xoff + q2 * 16; const int wq2 = xq >> 4, sq2 = (xq & 15) * 2;
+                                    const uint32_t g0 = kc[wq2], g1 = kc[wq2 + 1], h0 = kn[wq2], h1 = kn[wq2 + 1];
+                                    const uint32_t gv = sq2 ? (g0 >> sq2) | (g1 << (32 - sq2)) : g0, hv = sq2 ? (h0 >> sq2) | (h1 << (32 - sq2)) : h0;
+                                    const uint32_t dq = gv ^ pk[q2]; const int remq = rs.len - q2 * 16;
+                                    const uint32_t lq = remq >= 16 ? 0x55555555u : (0x55555555u >> (2 * (16 - remq)));
+                                    mmf += __builtin_popcount(((dq | (dq >> 1)) | hv) & lq);
+                                }
+                                (void)mml;
 #else
-                            for (int q2 = 0; q2 < nwr; q2++) mmf += __builtin_amdgcn_readlane(mml, q2);
+                                for (int q2 = 0; q2 < nwr; q2++) mmf += __builtin_amdgcn_readlane(mml, q2);
 #endif
-                            if (mmf >= mcut_cur) continue;
-                            ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
-                            if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
-                            if (v > bound) { bound = v; mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                                if (mmf >= mcut_cur) continue;
+                                FIG_COUNT(E, 21, lane == 0 ? 1 : 0);
+                                ex_acc += (unsigned long long)rs.len; const double v = fig_mle_serial<LDS>(SL, C, ncolE, pk, mt, rs.len, os + xoff, fbuf, lane, U.wsz);
+                                if (v > init) { FigBest y; y.v = v; y.o = os; ub = fig_best_merge(ub, y); }
+                                if (v > bound) { bound = v; mcut_cur = (int)(fig_log(bound) / lfmm) + 2; mcut_for = bound; }
+                            }
                         }
                     }
                     FIG_TICK(E, 17);
@@ -1150,6 +1322,69 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             }
         }
         FIG_TICK(E, 3);
+    }
+    // ---- (4) accept test + pile-up of the reads the lane-per-read path finished (:3848-3914 / :5128-5192), one read per lane
+    {
+        FIG_T0(E);
+        for (int r0 = 0; r0 < nU; r0 += U.nt) {
+            const int r = r0 + E.tid;
+            const bool mine = r < nU && mdone[r];
+            if (!fig_wave_any(mine)) continue;
+            bool acc = false; int of = 0, len = 0; double tlv = 0;
+            const uint32_t *pkl = U.packed;
+            FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
+            if (mine) {
+                len = U.u_len[ub + r];
+                of = E.scr.hint[r];                                  // never FIG_NOPOS on this path
+                tlv = -fig_log10(E.scr.hval[r]);
+                acc = tlv < U.cutoff;
+                if (mode == 1) acc = acc && E.scr.saved[r] == 1;
+                pkl = U.packed + U.u_woff[ub + r];
+                w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
+                E.scr.accf[r] = acc ? 1 : 0;
+            }
+            {   // integer pile-up (order-free)
+                const int nw2 = (len + 15) >> 4;
+                for (int wi = 0; fig_wave_any(acc && wi < nw2); wi++) {
+                    if (!(acc && wi < nw2)) continue;
+                    const uint32_t wd = pkl[wi];
+                    int nb = len - wi * 16; if (nb > 16) nb = 16;
+                    for (int jj = 0; jj < nb; jj++) {
+                        const int x = of + wi * 16 + jj;
+                        if (x >= 0 && x < gl && x < ncl) fig_atomic_add_i32(&nl[(int)((wd >> (2 * jj)) & 3) * nst + x], 1);
+                    }
+                }
+            }
+            if (mode == 0) {
+                const int nacc = fig_popc64(fig_ballot(acc));
+                if (lane == 0 && nacc) fig_atomic_add_i32(&S.valid_count, nacc);
+                if (acc) {
+                    E.scr.maxlv[r] = -tlv;
+                    E.scr.mark[r] = 1;
+                    E.scr.frp[r * 2] = of; E.scr.frp[r * 2 + 1] = len;
+                    if (G == G0) { E.scr.org[r * 2] = of; E.scr.org[r * 2 + 1] = len; }
+                    if (G0 <= 30) {
+                        const int val = of + len - G;
+                        if (of < 0 && val > 0) { if (-of > 3 && val > 3) fig_atomic_or_i32(&S.ucoverf, 1); }
+                        if (of < 0 && of + len > 0) { if (-of > 3) fig_atomic_or_i32(&S.umaxleftf, 1); }
+                        if (of > 0 && of < G && val > 0) { if (val > 3) fig_atomic_or_i32(&S.umaxrightf, 1); }
+                    }
+                }
+            } else {
+                const int nm = fig_popc64(fig_ballot(mine)), nrej = fig_popc64(fig_ballot(mine && !acc));
+                if (lane == 0) { fig_atomic_add_i32(&S.fin_i[6], nm); if (nrej) fig_atomic_add_i32(&S.fin_i[7], nrej); }
+                if (acc) {
+                    if (E.B->draw_pos) { E.B->draw_pos[ub + r] = of; E.B->draw_isz[ub + r] = w.tis0 + w.dir * of; }
+                    E.scr.fin[r * 2] = of; E.scr.fin[r * 2 + 1] = len;
+                    if (of == 0) fig_atomic_or_i32(&S.fin_i[4], 1);
+                    if (of + len == G) fig_atomic_or_i32(&S.fin_i[5], 1);
+                    if (of < 0 && of + len > 0) { fig_atomic_or_i32(&S.fin_i[0], 1); fig_atomic_max_i32(&S.fin_i[2], -of); }
+                    const int val = of + len - G;
+                    if (of < G && val > 0) { fig_atomic_or_i32(&S.fin_i[1], 1); fig_atomic_max_i32(&S.fin_i[3], val); }
+                }
+            }
+        }
+        FIG_TICK(E, 26);
     }
     E.flops += fl_acc; E.mle_alg += fl_acc; E.mle_exec += ex_acc;
     FIG_SYNC();
