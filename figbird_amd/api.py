@@ -107,6 +107,16 @@ def load_host_library() -> C.CDLL:
             raise RuntimeError("libfighost.so not built: run `python -m figbird_amd.build`")
         _host = C.CDLL(_build.HOSTLIB)
         _host.fighost_build_model.restype = C.c_int
+        _host.fighost_run_open.restype = C.c_void_p
+        _host.fighost_run_open.argtypes = [C.POINTER(C.c_char_p), C.c_char_p, C.c_int]
+        _host.fighost_run_close.argtypes = [C.c_void_p]; _host.fighost_run_close.restype = None
+        _host.fighost_run_ngaps.argtypes = [C.c_void_p]; _host.fighost_run_ngaps.restype = C.c_int64
+        _host.fighost_run_sizes.argtypes = [C.c_void_p, c_i32_p, c_i64_p, c_i64_p]
+        _host.fighost_run_params.argtypes = [C.c_void_p, c_i32_p]
+        _host.fighost_run_message.argtypes = [C.c_void_p, C.c_int]; _host.fighost_run_message.restype = C.c_char_p
+        _host.fighost_run_model.argtypes = [C.c_void_p, C.POINTER(FigModel)]
+        _host.fighost_run_shard.argtypes = [C.c_void_p, c_i64_p, C.c_int64, C.POINTER(FigGapBatch), c_i64_p, c_i64_p]
+        _host.fighost_run_write.argtypes = [C.c_void_p, c_i32_p, c_i32_p, c_i64_p, C.c_char_p, c_i32_p, c_i32_p, c_i32_p, C.c_char_p, C.c_int]
     return _host
 
 
@@ -246,6 +256,7 @@ class FillResult:
     read_maxlv: Optional[np.ndarray] = None  # plane (ii): [n_gaps, debug_cand, plane_reads] per-read E-step maximum
     str_off: Optional[np.ndarray] = None   # int64[n+1]: gap g's string is raw[str_off[g]:str_off[g+1]]
     raw: Optional[np.ndarray] = None       # uint8: all gap strings back to back, as the C ABI wrote them
+    draw: Optional[tuple] = None           # (draw_pos, draw_isz, draw_len) planes of fig_gap_results, when requested
 
     @property
     def filled_bases(self) -> int:
@@ -277,6 +288,12 @@ class Engine:
     def set_model(self, model: Model):
         self._model = model
         self._cm = model.cstruct()
+        self._check(self.lib.fig_ctx_set_model(self.ctx, C.byref(self._cm)), "fig_ctx_set_model")
+
+    def set_model_struct(self, cm: "FigModel"):
+        """Model given as a ready `fig_model` (pointers owned by the caller, e.g. libfighost's run handle)."""
+        self._model = None
+        self._cm = cm
         self._check(self.lib.fig_ctx_set_model(self.ctx, C.byref(self._cm)), "fig_ctx_set_model")
 
     def upload(self, batch: GapBatch):
@@ -324,6 +341,27 @@ class Engine:
 
     def free_batch(self):
         self.lib.fig_batch_free(self.ctx)
+
+    def fill_struct(self, cbatch: "FigGapBatch", n_ureads: int, n_preads: int, draw: bool = True) -> FillResult:
+        """fig_fill_gaps on a caller-built `fig_gap_batch` (e.g. a shard view from libfighost's run handle), with the
+        per-read draw planes; returns a FillResult whose `draw` field holds (draw_pos, draw_isz, draw_len)."""
+        n = int(cbatch.n_gaps)
+        cap = int(self.lib.fig_results_capacity(C.byref(self._cm), C.byref(cbatch))) if n > 0 else 1
+        fl = np.zeros(max(n, 1), dtype=np.int32); gt = np.zeros(max(n, 1), dtype=np.int32)
+        so = np.zeros(n + 1, dtype=np.int64); st = np.zeros(max(cap, 1), dtype=np.uint8)
+        r = FigGapResults()
+        r.filled_len = _p(fl, c_i32_p); r.gaptofill = _p(gt, c_i32_p); r.str_off = _p(so, c_i64_p)
+        r.str = C.cast(st.ctypes.data, C.c_char_p); r.str_capacity = len(st)
+        nr = n_ureads + n_preads
+        dpos = np.full(max(nr, 1), np.iinfo(np.int32).min, dtype=np.int32); disz = np.zeros(max(nr, 1), dtype=np.int32)
+        dlen = np.full(max(2 * n, 1), -1, dtype=np.int32)
+        if draw:
+            r.draw_pos = _p(dpos, c_i32_p); r.draw_isz = _p(disz, c_i32_p); r.draw_len = _p(dlen, c_i32_p)
+        if n > 0:
+            self._check(self.lib.fig_fill_gaps(self.ctx, C.byref(cbatch), C.byref(r)), "fig_fill_gaps")
+        res = FillResult(fl[:n].copy(), gt[:n].copy(), None, None, str_off=so, raw=st)
+        res.draw = (dpos[:nr], disz[:nr], dlen[:2 * n])
+        return res
 
     def fill(self, batch: GapBatch, debug_cand: int = 0, plane_cols: int = 0, plane_reads: int = 0) -> FillResult:
         self.upload(batch)

@@ -607,3 +607,103 @@ extern "C" int fighost_build_model(const char *contig_file, const char *tmp_dir,
     stats3[0] = M.insertSizeMean; stats3[1] = M.leftSD; stats3[2] = M.rightSD;
     return 0;
 }
+
+// ------------------------------------------------------------------ run handle (libfighost.so)
+// One gap-fill run as an object, for the multi-GPU launcher (figbird_amd/figfill_mp.py): every rank opens the run (same
+// inputs, same model), fills a SHARD of the gap set through the C ABI, and rank 0 writes the four output files from the
+// all-gathered results.  This is the role of FillGaps.cpp:456-649 (gap -> worker allocation), :668-679 (fan-out) and
+// :688-926 (merge + scaffold rebuild) with GPUs in place of `system("g++ Figbird.cpp ...")` workers.
+namespace {
+struct Run {
+    fighost::RunArgs a;
+    fighost::Scaffold sc;
+    fighost::Batch B, sub;
+    fighost::Model M;
+};
+void set_err(char *err, int cap, const std::string &m) { if (err && cap > 0) { snprintf(err, (size_t)cap, "%s", m.c_str()); } }
+}  // namespace
+
+extern "C" void *fighost_run_open(const char *const *argv15, char *err, int errcap) {
+    Run *r = new Run();
+    fighost::RunArgs &a = r->a;
+    a.contigFile = argv15[0]; a.D = atoi(argv15[1]); a.read_length = atoi(argv15[2]); a.script_itr = atoi(argv15[3]);
+    a.partial_flag = atoi(argv15[4]); a.unmapped = atoi(argv15[5]); a.num_threads = atoi(argv15[6]); a.mapFile = argv15[7];
+    a.tmp = argv15[8]; a.gapsDir = argv15[9]; a.neg_overlap = atoi(argv15[10]); a.partial_len = atoi(argv15[11]);
+    a.trim = atoi(argv15[12]); a.setinputmean = atoi(argv15[13]); a.isz = atoi(argv15[14]);
+    a.unm_limit = 400;
+    std::string e;
+    if (!fighost::load_scaffold(a.contigFile, r->sc, e) || !fighost::load_batch(a, r->sc, r->B, e) || !fighost::build_model(a, r->sc, r->M, e)) {
+        set_err(err, errcap, e); delete r; return nullptr;
+    }
+    return r;
+}
+extern "C" void fighost_run_close(void *h) { delete (Run *)h; }
+extern "C" int64_t fighost_run_ngaps(void *h) { return (int64_t)((Run *)h)->B.gap_contig.size(); }
+extern "C" int fighost_run_sizes(void *h, int32_t *gap_len, int64_t *n_u, int64_t *n_p) {
+    const fighost::Batch &B = ((Run *)h)->B;
+    for (size_t g = 0; g < B.gap_contig.size(); g++) {
+        gap_len[g] = B.gap_len[g]; n_u[g] = B.u_read_off[g + 1] - B.u_read_off[g]; n_p[g] = B.p_read_off[g + 1] - B.p_read_off[g];
+    }
+    return 0;
+}
+extern "C" int fighost_run_params(void *h, int32_t *out6) {        // read length, partial_len, unmapped flag, unm_limit, messages, -
+    const Run *r = (Run *)h;
+    out6[0] = r->M.maxReadLength; out6[1] = r->a.partial_len; out6[2] = r->a.unmapped; out6[3] = r->a.unm_limit; out6[4] = (int32_t)r->B.messages.size(); out6[5] = 0;
+    return 0;
+}
+extern "C" const char *fighost_run_message(void *h, int i) { return ((Run *)h)->B.messages[(size_t)i].c_str(); }
+extern "C" int fighost_run_model(void *h, fig_model *out) { Run *r = (Run *)h; r->M.fill(*out, r->a); return 0; }
+
+// Sub-batch of the gaps `ids` (any order; kept in that order), owned by the handle until the next call.
+extern "C" int fighost_run_shard(void *h, const int64_t *ids, int64_t n, fig_gap_batch *out, int64_t *n_ureads, int64_t *n_preads) {
+    Run *r = (Run *)h;
+    const fighost::Batch &B = r->B;
+    fighost::Batch &S = r->sub;
+    S = fighost::Batch();
+    S.u_read_off.push_back(0); S.p_read_off.push_back(0); S.u_seq_off.push_back(0); S.p_seq_off.push_back(0);
+    const int64_t ng = (int64_t)B.gap_contig.size();
+    for (int64_t k = 0; k < n; k++) {
+        const int64_t g = ids[k];
+        if (g < 0 || g >= ng) return -1;
+        S.gap_contig.push_back(B.gap_contig[g]); S.gap_start.push_back(B.gap_start[g]); S.gap_len.push_back(B.gap_len[g]);
+        for (int q = 0; q < 3; q++) S.gap_stat2.push_back(B.gap_stat2[g * 3 + q]);
+        S.gap_fillflag.push_back(B.gap_fillflag[g]);
+        for (int64_t i = B.u_read_off[g]; i < B.u_read_off[g + 1]; i++) {
+            S.u_anchor_pos.push_back(B.u_anchor_pos[i]); S.u_is_reverse.push_back(B.u_is_reverse[i]);
+            S.u_seq.append(B.u_seq, (size_t)B.u_seq_off[i], (size_t)(B.u_seq_off[i + 1] - B.u_seq_off[i]));
+            S.u_seq_off.push_back((int64_t)S.u_seq.size());
+        }
+        S.u_read_off.push_back((int64_t)S.u_anchor_pos.size());
+        for (int64_t i = B.p_read_off[g]; i < B.p_read_off[g + 1]; i++) {
+            S.p_clipped_index.push_back(B.p_clipped_index[i]); S.p_match.push_back(B.p_match[i]); S.p_pos.push_back(B.p_pos[i]); S.p_ref_pos.push_back(B.p_ref_pos[i]);
+            S.p_seq.append(B.p_seq, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
+            S.p_qual.append(B.p_qual, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
+            S.p_seq_off.push_back((int64_t)S.p_seq.size());
+        }
+        S.p_read_off.push_back((int64_t)S.p_clipped_index.size());
+    }
+    S.view(*out, r->sc);
+    *n_ureads = (int64_t)S.u_anchor_pos.size(); *n_preads = (int64_t)S.p_clipped_index.size();
+    return 0;
+}
+
+// gapout.txt, draw.txt, filledContigs.fa, Ncount.txt of the WHOLE gap set from arrays in global gap / read order
+// (draw_*: [all unmapped reads..., all partial reads...] as in fig_gap_results).
+extern "C" int fighost_run_write(void *h, const int32_t *filled_len, const int32_t *gaptofill, const int64_t *str_off, const char *str,
+                                 const int32_t *draw_pos, const int32_t *draw_isz, const int32_t *draw_len, char *err, int errcap) {
+    Run *r = (Run *)h;
+    const size_t ng = r->B.gap_contig.size();
+    const size_t nr = r->B.u_anchor_pos.size() + r->B.p_clipped_index.size();
+    fighost::Results R;
+    R.filled_len.assign(filled_len, filled_len + ng); R.gaptofill.assign(gaptofill, gaptofill + ng);
+    R.str_off.assign(str_off, str_off + ng + 1);
+    R.str.assign(str, str + (size_t)str_off[ng]);
+    if (draw_pos && draw_isz && draw_len) {
+        R.draw_pos.assign(draw_pos, draw_pos + nr); R.draw_isz.assign(draw_isz, draw_isz + nr); R.draw_len.assign(draw_len, draw_len + 2 * ng);
+    }
+    std::string e;
+    if (!fighost::write_gapout(r->a, r->B, R, e) || !fighost::write_draw(r->a, r->B, R, e) || !fighost::write_scaffold(r->a, r->sc, r->B, R, e)) {
+        set_err(err, errcap, e); return -1;
+    }
+    return 0;
+}

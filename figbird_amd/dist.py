@@ -39,47 +39,50 @@ def estimate_cost(gap_len: np.ndarray, n_reads: np.ndarray, read_len: int, unmap
     return R * W * read_len * np.maximum(cand, 1.0) * its + 1.0
 
 
-def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None):
-    """All-gather the shard results as packed byte buffers: one 2-word header exchange, then ONE all-gather of a
-    single uint8 buffer per rank laid out [ids | filled_len | gaptofill | gap strings], straight from the numpy
-    arrays the C ABI filled (no per-gap Python strings on the way).  `res` is an api.FillResult (fields
-    filled_len, gaptofill, str_off, raw).  Returns (filled_len[n_total], gaptofill[n_total], strings) on every
-    rank, `strings` being a PackedStrings (bytes of gap g = strings[g]) in global gap order."""
+def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None, extras: Sequence[np.ndarray] = ()):
+    """All-gather the shard results as packed byte buffers: one small header exchange, then ONE all-gather of a
+    single uint8 buffer per rank laid out [ids | filled_len | gaptofill | extras... | gap strings], straight from the
+    numpy arrays the C ABI filled (no per-gap Python strings on the way).  `res` is an api.FillResult (fields
+    filled_len, gaptofill, str_off, raw); `extras` are optional int32 arrays of any length that travel with the
+    shard (figfill_mp sends the draw planes this way).  Returns (filled_len[n_total], gaptofill[n_total], strings)
+    -- `strings` a PackedStrings in global gap order -- and, when extras were given, a fourth element: per rank,
+    the tuple (ids, extras...) as received."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size() if dist.is_initialized() else 1
-    ids_a = np.asarray(ids, dtype=np.int32)
+    ids_a = np.ascontiguousarray(ids, dtype=np.int32)
     n = len(ids_a)
-    fl_a = np.asarray(res.filled_len[:n], dtype=np.int32)
-    gt_a = np.asarray(res.gaptofill[:n], dtype=np.int32)
+    fl_a = np.ascontiguousarray(res.filled_len[:n], dtype=np.int32)
+    gt_a = np.ascontiguousarray(res.gaptofill[:n], dtype=np.int32)
     nbytes = int(res.str_off[n]) if n else 0
-    payload = np.asarray(res.raw[:nbytes], dtype=np.uint8)
+    payload = np.ascontiguousarray(res.raw[:nbytes], dtype=np.uint8)
+    ex = [np.ascontiguousarray(e, dtype=np.int32) for e in extras]
+    ne = len(ex)
     if world == 1:
-        heads = [(n, nbytes)]
-        blobs = [(ids_a, fl_a, gt_a, payload)]
+        blobs = [(ids_a, fl_a, gt_a, payload, ex)]
     else:
         dev = device if device is not None else torch.device("cpu")
-        head = torch.tensor([n, nbytes], dtype=torch.int64, device=dev)
-        hs = [torch.zeros(2, dtype=torch.int64, device=dev) for _ in range(world)]
+        head = torch.tensor([n, nbytes] + [len(e) for e in ex], dtype=torch.int64, device=dev)
+        hs = [torch.zeros(2 + ne, dtype=torch.int64, device=dev) for _ in range(world)]
         dist.all_gather(hs, head)
-        heads = [(int(h[0]), int(h[1])) for h in hs]
-        max_n = max(h[0] for h in heads); max_b = max(h[1] for h in heads)
-        size = 12 * max_n + max_b + 8
-        mine = np.zeros(size, dtype=np.uint8)
-        mine[0:4 * n] = ids_a.view(np.uint8)
-        mine[4 * max_n:4 * max_n + 4 * n] = fl_a.view(np.uint8)
-        mine[8 * max_n:8 * max_n + 4 * n] = gt_a.view(np.uint8)
-        mine[12 * max_n:12 * max_n + nbytes] = payload
+        heads = [[int(v) for v in h.cpu()] for h in hs]
+        mx = [max(h[k] for h in heads) for k in range(2 + ne)]
+        seg = [4 * mx[0]] * 3 + [4 * mx[2 + k] for k in range(ne)] + [mx[1] + 8]
+        off = np.concatenate([[0], np.cumsum(seg)]).astype(np.int64)
+        mine = np.zeros(int(off[-1]), dtype=np.uint8)
+        for k, arr in enumerate([ids_a, fl_a, gt_a] + ex):
+            mine[off[k]:off[k] + 4 * len(arr)] = arr.view(np.uint8)
+        mine[off[3 + ne]:off[3 + ne] + nbytes] = payload
         buf = torch.from_numpy(mine).to(dev)
         bufs = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(bufs, buf)
         blobs = []
         for r in range(world):
             a = bufs[r].cpu().numpy()
-            nr, nb = heads[r]
-            blobs.append((a[0:4 * nr].view(np.int32), a[4 * max_n:4 * max_n + 4 * nr].view(np.int32),
-                          a[8 * max_n:8 * max_n + 4 * nr].view(np.int32), a[12 * max_n:12 * max_n + nb]))
+            nr, nb = heads[r][0], heads[r][1]
+            i32 = lambda k, cnt: a[off[k]:off[k] + 4 * cnt].view(np.int32)
+            blobs.append((i32(0, nr), i32(1, nr), i32(2, nr), a[off[3 + ne]:off[3 + ne] + nb], [i32(3 + k, heads[r][2 + k]) for k in range(ne)]))
     gid = np.concatenate([b[0] for b in blobs]) if blobs else np.zeros(0, dtype=np.int32)
     flc = np.concatenate([b[1] for b in blobs]); gtc = np.concatenate([b[2] for b in blobs])
     pay = np.concatenate([b[3] for b in blobs])
@@ -93,6 +96,8 @@ def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None):
     total = int(off[-1])
     idx = np.repeat(src_start[perm] - off[:-1][gid[perm]], lens[perm]) + np.arange(total, dtype=np.int64)
     raw = pay[idx] if total else np.zeros(0, dtype=np.uint8)
+    if ne:
+        return fl, gt, PackedStrings(off, raw), [(b[0],) + tuple(b[4]) for b in blobs]
     return fl, gt, PackedStrings(off, raw)
 
 

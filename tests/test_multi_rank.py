@@ -67,3 +67,46 @@ def test_two_rank_shard_and_gather_reproduces_the_reference(tmp_path):
     for rank, mine, fl, gt, ss in outs:                     # every rank holds the full, identical result
         assert fl == [int(e[4]) for e in exp]
         assert ss == [e[5] if len(e) > 5 else "" for e in exp]
+
+
+def _mp_worker(rank, world, port, root, name, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, util.ROOT)
+    from figbird_amd import figfill_mp
+    os.chdir(root)
+    rc = figfill_mp.run(util.meta(root)["fillgaps_argv"], backend="gloo", lib_path=util.EMULIB, device_index=0, verbose=False)
+    q.put((rank, rc))
+
+
+@pytest.mark.parametrize("name,world", [("unmapped_mid_err", 2), ("partial_brackets", 2), ("edge_contig_ends", 3)])
+def test_figfill_mp_writes_the_reference_files(name, world, tmp_path):
+    """The multi-GPU product path (figbird_amd.figfill_mp: run handle -> LPT shards -> C ABI -> one packed all-gather ->
+    rank 0 writes) on `world` gloo ranks: gapout.txt, draw.txt, filledContigs.fa and Ncount.txt byte-identical to the
+    reference's (numthreads=1 goldens)."""
+    import torch.multiprocessing as mp
+    root = util.extract_golden(name, str(tmp_path))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_mp_worker, args=(r, world, port, root, name, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(rc == 0 for _, rc in outs)
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+def test_figfill_mp_single_rank_without_a_launcher(tmp_path, monkeypatch):
+    """N = 1: no process group, same files."""
+    from figbird_amd import figfill_mp
+    root = util.extract_golden("partial_small", str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.chdir(root)
+    assert figfill_mp.run(util.meta(root)["fillgaps_argv"], lib_path=util.EMULIB, device_index=0, verbose=False) == 0
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
