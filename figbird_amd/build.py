@@ -15,6 +15,7 @@ LIBDIR = os.path.join(PKG, "lib")
 BINDIR = os.path.join(PKG, "bin")
 LIB = os.path.join(LIBDIR, "libfighip.so")
 FIGFILL = os.path.join(BINDIR, "figfill")
+FIGTOOL = os.path.join(BINDIR, "figtool")
 HOSTLIB = os.path.join(LIBDIR, "libfighost.so")
 
 HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
@@ -65,12 +66,15 @@ def build_figfill(force: bool = False) -> str:
     os.makedirs(BINDIR, exist_ok=True)
     host, hdrs, libs = _host_sources()
     main_cpp = os.path.join(host, "figfill_main.cpp")
-    srcs = hdrs + libs + [main_cpp, os.path.join(ROOT, "include", "figbird_hip.h")]
+    srcs = hdrs + libs + [main_cpp, os.path.join(ROOT, "include", "figbird_hip.h")]      # (figtool_main.cpp is built below)
     common = ["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread"]
     if force or not _newer(FIGFILL, srcs + [LIB]):
         _run(common + ["-o", FIGFILL, main_cpp] + libs + ["-L" + LIBDIR, "-lfighip", "-Wl,-rpath,$ORIGIN/../lib"])
     if force or not _newer(HOSTLIB, srcs):
         _run(common + ["-fPIC", "-shared", "-o", HOSTLIB] + libs)
+    tool_cpp = os.path.join(host, "figtool_main.cpp")
+    if force or not _newer(FIGTOOL, hdrs + libs + [tool_cpp]):
+        _run(common + ["-o", FIGTOOL, tool_cpp] + libs)
     return FIGFILL
 
 
