@@ -20,7 +20,10 @@ FIG_D void fig_gap_begin(FigEng &E) {
         S.left_max = 0; S.right_min = 0; S.discont_or_not = 0;
         S.psr_temp[0] = S.psr_temp[1] = S.psr_final[0] = S.psr_final[1] = -1;
         S.umaxleftf = S.umaxrightf = S.ucoverf = 0;
-        S.num_itr = 0; S.overlap_threshold = 0; S.gaptofill = 0;
+        // overlap_threshold is a file-level global in the reference (Figbird.cpp:103), 0 until the first candidate loop of the
+        // process reaches :6317 and 5 ever after: a gap sees 5 if an EARLIER gap got there (g.pad, worked out by the packer in
+        // file order = the numthreads=1 order) or once its own loop does (fig_eval_candidate / fig_spec_replay)
+        S.num_itr = 0; S.overlap_threshold = g.pad ? 5 : 0; S.gaptofill = 0;
         S.gl_len = S.gr_len = S.pl_len = S.pr_len = 0;
         S.cons_len = 1; E.scr.cons[0] = 4;
         S.best_len = S.cur_len = S.prev_len = S.orig_len = 0;
@@ -405,6 +408,7 @@ FIG_D void fig_spec_replay(FigEng &E, const FigScr &work, const FigPersist &P, i
             S.left = h->left; S.right = h->right; S.side_limit = h->side_limit; S.cons_len = h->cons_len;
             S.partial_read_len = h->partial_read_len; S.partial_read_count = h->partial_read_count;
             S.n_place += h->n_place; S.flops_useful += h->flops;
+            if (!h->side_break && !(h->fill != 0 && S.L.inr)) S.overlap_threshold = 5;      // this candidate's loop body got to Figbird.cpp:6317
         }
         FIG_SYNC();
         if (h->G == G0 && !h->side_break && !(h->fill != 0 && S.L.inr)) {     // this candidate's placeReads ran with gapLength == originalGap

@@ -196,6 +196,25 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
     }
     K.str_total = str_total; K.str_off[ng] = str_total;
     K.capG = (K.capG + 7) & ~7;
+    {   // which gaps find the reference's global overlap_threshold already at 5 (set by an earlier gap's candidate loop,
+        // Figbird.cpp:6317): a loop gets there unless its first initialize() leaves side_limit < 10 (:6303; computable here from
+        // the gap's distance to the contig ends, initialize_start_end :2269-2296) or closes the gap by a negative overlap (:6306;
+        // only the device knows -- such a predecessor is taken as having got there, the one approximation in this rule)
+        bool reached = false;
+        for (int64_t g = 0; g < ng; g++) {
+            FigDevGap &d = K.gaps[g];
+            d.pad = reached ? 1 : 0;
+            int sl = 30;
+            const bool skip = d.fillflag == -1;
+            const int gmin = skip ? d.G0 : (int)(d.G0 * d.gpf1);
+            const int Gs[2] = {d.G0, gmin};
+            for (int G : Gs) {
+                if (d.gapStart - m->max_distance < 0) sl = std::min<int64_t>(sl, d.gapStart);
+                if (d.gapStart + G + m->max_distance > d.contigLen) sl = (int)std::min<int64_t>(sl, d.contigLen - (d.gapStart + G));
+            }
+            if (sl >= 10) reached = true;
+        }
+    }
     // ---- launch classes by the longest candidate a gap can reach (LDS columns); within a class the most
     // expensive gaps come first.  gmax: candidate range (:6237-6238), checkGapReads probes (:6121-6153).
     std::vector<int> gmax(ng, 8);
@@ -210,7 +229,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         long long off = 0;
         for (int64_t g = 0; g < ng; g++) {
             FigDevGap &d = K.gaps[g];
-            d.capGg = (gmax[g] + 7) & ~7; d.rangeCap = gap_range(d.G0, d.gpf1, d.gpf2); d.nslots = K.nslots; d.pad = 0;
+            d.capGg = (gmax[g] + 7) & ~7; d.rangeCap = gap_range(d.G0, d.gpf1, d.gpf2); d.nslots = K.nslots;
             d.persistOff = off;
             off += (fig_persist_layout(nullptr, d.capGg, d.nU, d.nP, d.rangeCap, d.nslots, state_bytes, nullptr) + 255) & ~255LL;
         }

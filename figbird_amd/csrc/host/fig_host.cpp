@@ -385,7 +385,38 @@ static char comp(char ch) {                 // reverse(), Figbird.cpp:1427-1449
     switch (ch) { case 'A': case 'a': return 'T'; case 'C': case 'c': return 'G'; case 'G': case 'g': return 'C'; case 'T': case 't': return 'A'; default: return 'N'; }
 }
 
+// per-gap line source: (is_partial, gap, lines) -> found?
+typedef std::function<bool(bool, size_t, std::vector<std::string> &)> GapLines;
+static bool load_batch_src(const RunArgs &a, const Scaffold &sc, const GapLines &src, Batch &B, std::string &err);
+
 bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &B, std::string &err) {
+    return load_batch_src(a, sc, [&](bool partial, size_t g, std::vector<std::string> &lines) {
+        return read_lines(a.gapsDir + (partial ? "partial_gaps_" : "gaps_") + std::to_string(g) + ".sam", lines); }, B, err);
+}
+
+static void split_lines(const std::string &text, std::vector<std::string> &out) {      // as fgets() would cut them (kMaxRec-1 characters at most)
+    out.clear();
+    size_t p = 0;
+    while (p < text.size()) {
+        size_t e = text.find('\n', p);
+        size_t end = e == std::string::npos ? text.size() : e + 1;
+        while (end - p > (size_t)kMaxRec - 1) { out.emplace_back(text, p, (size_t)kMaxRec - 1); p += (size_t)kMaxRec - 1; }
+        out.emplace_back(text, p, end - p);
+        p = end;
+    }
+}
+
+bool load_batch_mem(const RunArgs &a, const Scaffold &sc, const std::vector<std::string> *gaps_text, const std::vector<std::string> *partial_text,
+                    Batch &B, std::string &err) {
+    return load_batch_src(a, sc, [&](bool partial, size_t g, std::vector<std::string> &lines) {
+        const std::vector<std::string> *t = partial ? partial_text : gaps_text;
+        lines.clear();
+        if (!t) return partial;                         // no partial texts: empty files (the reference needs them to exist); no gaps texts: missing
+        if (g < t->size()) split_lines((*t)[g], lines);
+        return true; }, B, err);
+}
+
+static bool load_batch_src(const RunArgs &a, const Scaffold &sc, const GapLines &src, Batch &B, std::string &err) {
     std::vector<std::string> gi, st2;
     if (!read_lines(a.tmp + "gapInfo.txt", gi)) { err = "Couldn't open gapinfo"; return false; }
     if (!read_lines(a.tmp + "stat2.txt", st2)) { err = "Couldn't open stat2.txt"; return false; }
@@ -408,7 +439,7 @@ bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &B, std::string &err
         std::vector<std::string> lines;
         if (a.unmapped == 1) {
             // findcount_file(...,0) :6686-6711 then parseUnmapped :5661-5767
-            if (!read_lines(a.gapsDir + "gaps_" + gs + ".sam", lines)) { err = "missing gaps_" + gs + ".sam"; return false; }
+            if (!src(false, g, lines)) { err = "missing gaps_" + gs + ".sam"; return false; }
             long pairs = (long)(lines.size() / 2);
             int r_count1 = (int)pairs;
             if (pairs > kReadCap) { B.messages.push_back("Gap = " + gs + "\tReads = " + std::to_string(pairs)); r_count1 = kReadCap; fillflag = -1; }
@@ -444,7 +475,7 @@ bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &B, std::string &err
             }
         }
         B.u_read_off.push_back((int64_t)B.u_anchor_pos.size());
-        if (!read_lines(a.gapsDir + "partial_gaps_" + gs + ".sam", lines)) { err = "missing partial_gaps_" + gs + ".sam (the reference fopen()s it unconditionally)"; return false; }
+        if (!src(true, g, lines)) { err = "missing partial_gaps_" + gs + ".sam (the reference fopen()s it unconditionally)"; return false; }
         size_t keep = std::min(lines.size(), (size_t)kReadCap + 1);
         for (size_t k = 0; k < keep; k++) {
             std::vector<char> c1(lines[k].begin(), lines[k].end()); c1.push_back(0);

@@ -5,6 +5,7 @@
 #ifndef FIG_HOST_H
 #define FIG_HOST_H
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <vector>
 #include "../../../include/figbird_hip.h"
@@ -51,6 +52,12 @@ struct Batch {                      // owns the arrays fig_gap_batch points into
 
 // gapInfo.txt, stat2.txt, gaps_<g>.sam (parseUnmapped, Figbird.cpp:5661-5767), partial_gaps_<g>.sam
 bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &out, std::string &err);
+
+// The same parser fed from memory instead of per-gap files: `gaps_text[g]` / `partial_text[g]` are the texts the binning
+// stage (fig_sam.h) would have written to gaps_<g>.sam / partial_gaps_<g>.sam (either may be empty = "no such files":
+// unmapped-mode reads are then absent, partial files count as empty).  gapInfo.txt / stat2.txt still come from a.tmp.
+bool load_batch_mem(const RunArgs &a, const Scaffold &sc, const std::vector<std::string> *gaps_text, const std::vector<std::string> *partial_text,
+                    Batch &out, std::string &err);
 
 struct Results {
     std::vector<int32_t> filled_len, gaptofill, draw_pos, draw_isz, draw_len;

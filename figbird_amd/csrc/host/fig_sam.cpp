@@ -395,7 +395,7 @@ bool load_contigs(const std::string &path, std::vector<std::string> &contigs, st
 
 }  // namespace
 
-int preprocess(const Args &a, Binned &out, std::string &err, bool write_files) {
+int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
     State S; S.a = a;
     // ---- genome reduction: gap ordinal -> contig index of the UNREDUCED genome (:1883-2007)
     std::map<int, int> contignums;
@@ -562,7 +562,7 @@ int preprocess(const Args &a, Binned &out, std::string &err, bool write_files) {
     // ---- results
     out.gaps = S.gaps; out.gap_files = S.gap_text; out.partial_files = S.partial_text; out.perfect_gap = S.perfect_gap; out.perfect_len = S.perfect_len;
     out.totalCount = S.totalCount; out.unCount = S.unCount; out.maxReadLength = S.maxReadLength;
-    if (write_files) {
+    if (write_mode) {
         auto put = [&](const std::string &path, const std::string &text) { FILE *f = fopen(path.c_str(), "w"); if (!f) return false; fwrite(text.data(), 1, text.size(), f); fclose(f); return true; };
         if (!put(a.tmpDir + "gapInfo.txt", gapInfo)) { err = "can't write gapInfo.txt"; return 1; }
         if (!put(a.outFile, S.myout)) { err = "Can't create myout file"; return 1; }
@@ -572,7 +572,7 @@ int preprocess(const Args &a, Binned &out, std::string &err, bool write_files) {
         std::string st2;
         for (size_t g = 0; g < ng; g++) { snprintf(buf, sizeof buf, "%d\t%d\t%d\n", 1, S.perfect_gap[g], S.perfect_len[g]); st2 += buf; }
         if (!put(a.tmpDir + "stat2.txt", st2)) { err = "can't write stat2.txt"; return 1; }
-        for (size_t g = 0; g < ng; g++) {
+        for (size_t g = 0; g < ng && write_mode == 1; g++) {
             const std::string nm = a.gapsDir + (a.samflag == 2 ? "gaps_" : "partial_gaps_") + std::to_string(g) + ".sam";
             if (!put(nm, a.samflag == 2 ? S.gap_text[g] : S.partial_text[g])) { err = "can't write " + nm; return 1; }
         }

@@ -31,7 +31,9 @@ struct Binned {
 };
 
 // Runs the whole stage; returns the process exit code (0 ok, 1 on the reference's "Can't open ..." errors).
-int preprocess(const Args &a, Binned &out, std::string &err, bool write_files = true);
+// write_mode: 1 = every file the reference writes; 2 = only the run-level files (gapInfo/stat/stat2/myout + reduced reads),
+// the per-gap texts staying in `out` for an in-memory hand-over to the fill; 0 = nothing.
+int preprocess(const Args &a, Binned &out, std::string &err, int write_mode = 1);
 // argv[0] = "preprocess", argv[1..13] = the reference's arguments
 int preprocess_main(int argc, char **argv);
 

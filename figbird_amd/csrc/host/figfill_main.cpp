@@ -10,9 +10,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 #include <chrono>
 
 #include "fig_host.h"
+#include "fig_sam.h"
 
 using namespace fighost;
 
@@ -38,7 +40,26 @@ int main(int argc, char **argv) {
     Scaffold sc;
     if (!load_scaffold(a.contigFile, sc, err)) return fail(err);
     Batch B;
-    if (!load_batch(a, sc, B, err)) return fail(err);
+    // FIGFILL_SAM="<maxD1>:<frag.sam>[;<maxD2>:<jump.sam>]": ingest the aligner's SAM in this process (the binning of
+    // Preprocess.cpp, fig_sam.h) and hand the per-gap reads to the fill in memory -- no gaps_<g>.sam / partial_gaps_<g>.sam
+    // files.  The run-level files (gapInfo/stat/stat2.txt, myout.sam) are still written: the model is built from them.
+    if (const char *spec = getenv("FIGFILL_SAM")) {
+        std::string sp(spec);
+        std::vector<std::pair<int, std::string>> libs;
+        size_t p = 0;
+        while (p < sp.size()) { size_t e = sp.find(';', p); if (e == std::string::npos) e = sp.size(); std::string it = sp.substr(p, e - p); size_t c = it.find(':');
+                                if (c != std::string::npos) libs.emplace_back(atoi(it.substr(0, c).c_str()), it.substr(c + 1)); p = e + 1; }
+        if (libs.empty() || (a.unmapped == 1 && libs.size() < 2)) return fail("figfill: FIGFILL_SAM needs <maxD>:<frag.sam> and, in unmapped mode, ;<maxD>:<jump.sam>");
+        figsam::Binned frag, jump;
+        for (size_t k = 0; k < libs.size() && k < 2; k++) {
+            figsam::Args pa;
+            pa.contigFile = a.contigFile; pa.maxDistance = libs[k].first; pa.samflag = (int)k + 1; pa.mapFile = libs[k].second; pa.outFile = a.mapFile;
+            pa.filledContigFile = a.contigFile; pa.reads1 = "r_1.fastq"; pa.reads2 = "r_2.fastq"; pa.gapsDir = a.gapsDir; pa.tmpDir = a.tmp; pa.default_setting = 1;
+            if (k == 1 && a.unmapped != 1) break;
+            if (figsam::preprocess(pa, k == 0 ? frag : jump, err, 2)) return fail(err);
+        }
+        if (!load_batch_mem(a, sc, a.unmapped == 1 ? &jump.gap_files : nullptr, &frag.partial_files, B, err)) return fail(err);
+    } else if (!load_batch(a, sc, B, err)) return fail(err);
     printf("Total # of gaps = %zu\n", B.gap_contig.size());
     for (const std::string &m : B.messages) printf("%s\n", m.c_str());
     Model M;

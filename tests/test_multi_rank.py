@@ -110,3 +110,17 @@ def test_figfill_mp_single_rank_without_a_launcher(tmp_path, monkeypatch):
     assert figfill_mp.run(util.meta(root)["fillgaps_argv"], lib_path=util.EMULIB, device_index=0, verbose=False) == 0
     for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+@pytest.mark.gpu
+def test_figfill_mp_on_the_device_single_rank(tmp_path, monkeypatch):
+    """The launcher's N = 1 path on the MI355X (libfighip.so through fig_fill_gaps): the reference's four files."""
+    from figbird_amd import figfill_mp
+    root = util.extract_golden("unmapped_small", str(tmp_path))
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.chdir(root)
+    assert figfill_mp.run(util.meta(root)["fillgaps_argv"], device_index=0, verbose=False) == 0
+    assert "libfighip.so" in open("/proc/self/maps").read()
+    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn

@@ -20,7 +20,7 @@ EMULIB = fbuild.EMULIB
 FIGFILL = pbuild.FIGFILL
 REF_FIGBIRD = os.path.join(fbuild.REFDIR, "Figbird.out")
 
-NON_FILL_GOLDENS = {"plumbing", "preprocess_boundary"}       # fixtures of the stages either side of the fill (tests/test_plumbing.py)
+NON_FILL_GOLDENS = {"plumbing", "preprocess_boundary", "pipeline_e2e"}       # fixtures of the stages either side of the fill (tests/test_plumbing.py)
 GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz") and f[:-7] not in NON_FILL_GOLDENS) if os.path.isdir(GOLDEN) else []
 FIGTOOL = pbuild.FIGTOOL
 
