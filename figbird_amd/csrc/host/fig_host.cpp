@@ -3,10 +3,17 @@
 #include "fig_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace fighost {
 
@@ -84,7 +91,8 @@ struct Counts {
 template <class F> void walk_cigar(const char *cigar, const char *delims, F f) {
     std::vector<char> tc(cigar, cigar + strlen(cigar) + 1);
     int totalLength = 0;
-    for (char *t = strtok(tc.data(), delims); t; t = strtok(nullptr, delims)) {
+    char *svc = nullptr;
+    for (char *t = strtok_r(tc.data(), delims, &svc); t; t = strtok_r(nullptr, delims, &svc)) {
         unsigned long n = (unsigned long)atoi(t);
         totalLength += (int)strlen(t);
         f(cigar[totalLength], n);
@@ -96,11 +104,12 @@ template <class F> void walk_cigar(const char *cigar, const char *delims, F f) {
 template <class F> void walk_md(const char *md, const std::vector<int> &inserts, const char *read, F f) {
     unsigned long mdLength = strlen(md) - 5;
     std::vector<char> tm(md, md + strlen(md) + 1);
-    strtok(tm.data(), ":");
-    strtok(nullptr, ":");
+    char *svm = nullptr;
+    strtok_r(tm.data(), ":", &svm);
+    strtok_r(nullptr, ":", &svm);
     int index = 0, totalLength = 0;
     char *temp;
-    while ((temp = strtok(nullptr, "ACGTN^\t\n ")) != nullptr) {
+    while ((temp = strtok_r(nullptr, "ACGTN^\t\n ", &svm)) != nullptr) {
         totalLength += (int)strlen(temp);
         if ((unsigned long)totalLength < mdLength) {
             char from = md[5 + totalLength];
@@ -258,6 +267,53 @@ long double error_prob(const Probs &p, const SamCols &s) {      // computeErrorP
 
 }  // namespace
 
+// ---- multi-threaded passes over myout.sam.  The reference re-parses the whole file twice in every one of
+// its worker processes (Figbird.cpp:7110-7133); here the file is mapped once and both passes are split over host threads.
+// Everything the passes accumulate is an integer count (position / type / length histograms, the gapProbs histogram), so the
+// merged result is the sequential one exactly.  The one order-dependent corner -- an insert of exactly maxInsertSize grows the
+// histogram and changes what later inserts do (:207-223) -- makes the caller fall back to the sequential pass.
+namespace {
+
+struct MapFile {
+    const char *p = nullptr; size_t n = 0; int fd = -1;
+    bool open(const std::string &path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st; if (fstat(fd, &st) != 0) { ::close(fd); fd = -1; return false; }
+        n = (size_t)st.st_size;
+        if (n == 0) { p = ""; return true; }
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) { ::close(fd); fd = -1; return false; }
+        p = (const char *)m;
+        return true;
+    }
+    ~MapFile() { if (p && n) munmap((void *)p, n); if (fd >= 0) ::close(fd); }
+};
+
+inline size_t line_end(const MapFile &f, size_t b) { const void *e = memchr(f.p + b, '\n', f.n - b); return e ? (size_t)((const char *)e - f.p) + 1 : f.n; }
+// copies the line at [b, e) as fgets(buf, kMaxRec) would return its first piece
+inline void copy_line(const MapFile &f, size_t b, size_t e, char *buf) { size_t len = std::min(e - b, (size_t)kMaxRec - 1); memcpy(buf, f.p + b, len); buf[len] = 0; }
+inline size_t next_line_start(const MapFile &f, size_t pos) { return pos == 0 ? 0 : line_end(f, pos - 1); }     // first line starting at or after pos
+
+std::string qname_at(const MapFile &f, size_t b) { size_t e = b; while (e < f.n && f.p[e] != '\t' && f.p[e] != '\n') e++; return std::string(f.p + b, e - b); }
+
+// start of the non-header line `back` lines before the line starting at b (b itself when back == 0); false if there are fewer
+bool line_before(const MapFile &f, size_t b, int back, size_t &out) {
+    size_t cur = b;
+    for (int k = 0; k < back; ) {
+        if (cur == 0) return false;
+        size_t prev = cur - 1;                       // the newline that ends the previous line
+        size_t s0 = prev;
+        while (s0 > 0 && f.p[s0 - 1] != '\n') s0--;
+        cur = s0;
+        if (f.p[cur] != '@') k++;
+    }
+    out = cur;
+    return true;
+}
+
+}  // namespace
+
 bool build_model(const RunArgs &a, const Scaffold &sc, Model &out, std::string &err) {
     Counts c;
     long totalCount = 0, unCount = 0;
@@ -278,44 +334,99 @@ bool build_model(const RunArgs &a, const Scaffold &sc, Model &out, std::string &
     std::string noErrorCigar = std::to_string(c.L) + "M";
     double inputMean = a.setinputmean == 1 ? a.isz : 0;
 
-    // pass 1 (Figbird.cpp:7110-7128)
-    FILE *mf = fopen(a.mapFile.c_str(), "r");
-    if (!mf) { err = "Can't open map file"; return false; }
-    char line[kMaxRec];
-    while (fgets(line, kMaxRec, mf)) {
-        if (line[0] == '@') continue;
-        SamCols s; split_sam(line, s);
-        if (!s.ok) continue;
-        if (s.nh == 1 && s.md[0] && s.md[5] != '^') {
-            long contigNo = atol(s.rname);
-            if (contigNo < 0 || contigNo >= sc.n()) { fclose(mf); err = "myout.sam: contig index out of range"; return false; }
-            if ((int)strlen(s.seq) > c.L) { fclose(mf); err = "myout.sam: read longer than maxReadLength"; return false; }
-            if ((double)(sc.off[contigNo + 1] - sc.off[contigNo]) > inputMean) update_insert_counts(c, s.tlen);
-            count_errors(c, s, noErrorCigar);
-            c.uniqueMappedReads++;
+    MapFile mf;
+    if (!mf.open(a.mapFile)) { err = "Can't open map file"; return false; }
+    int T = 1;
+    { const char *te = getenv("FIGFILL_THREADS"); unsigned hw = std::thread::hardware_concurrency(); T = te ? atoi(te) : (int)std::min<unsigned>(hw ? hw : 1, 16);
+      if (T < 1) T = 1; if (mf.n < ((size_t)4 << 20) && !te) T = 1; }
+    // line-aligned byte ranges
+    std::vector<size_t> cut((size_t)T + 1, mf.n);
+    for (int t = 0; t < T; t++) cut[t] = next_line_start(mf, mf.n / (size_t)T * (size_t)t);
+    cut[0] = 0;
+
+    // ---- pass 1 (Figbird.cpp:7110-7128): insert-size histogram + error position / type / length counts
+    auto pass1 = [&](size_t b, size_t e, Counts &cc, bool allow_resize, bool &need_seq, std::string &perr) {
+        char line[kMaxRec];
+        for (size_t pos = b; pos < e; ) {
+            size_t le = line_end(mf, pos);
+            if (mf.p[pos] != '@') {
+                copy_line(mf, pos, le, line);
+                SamCols s; split_sam(line, s);
+                if (s.ok && s.nh == 1 && s.md[0] && s.md[5] != '^') {
+                    long contigNo = atol(s.rname);
+                    if (contigNo < 0 || contigNo >= sc.n()) { perr = "myout.sam: contig index out of range"; return; }
+                    if ((int)strlen(s.seq) > cc.L) { perr = "myout.sam: read longer than maxReadLength"; return; }
+                    if ((double)(sc.off[contigNo + 1] - sc.off[contigNo]) > inputMean) {
+                        if (!allow_resize && s.tlen >= cc.maxInsertSize && s.tlen <= cc.MAX_INSERT_SIZE) { need_seq = true; return; }
+                        update_insert_counts(cc, s.tlen);
+                    }
+                    count_errors(cc, s, noErrorCigar);
+                    cc.uniqueMappedReads++;
+                }
+            }
+            pos = le;
+        }
+    };
+    bool seq1 = T == 1;
+    if (!seq1) {
+        std::vector<Counts> tc((size_t)T);
+        std::vector<char> need((size_t)T, 0); std::vector<std::string> errs((size_t)T);
+        std::vector<std::thread> th;
+        for (int t = 0; t < T; t++) {
+            Counts &z = tc[(size_t)t];
+            z.L = c.L; z.maxInsertSize = c.maxInsertSize; z.MAX_INSERT_SIZE = c.MAX_INSERT_SIZE;
+            z.insertCounts.assign((size_t)c.maxInsertSize, 0);
+            for (auto &r : z.errorTypes) for (long &v : r) v = 0;
+            for (long &v : z.baseCounts) v = 0;
+            z.errorPos.assign(c.L, 0); z.inPos.assign(c.L, 0); z.inLengths.assign(c.L, 0); z.delPos.assign(c.L, 0); z.delLengths.assign(c.L, 0); z.readLengths.assign(c.L, 0);
+            th.emplace_back([&, t] { bool nd = false; pass1(cut[(size_t)t], cut[(size_t)t + 1], tc[(size_t)t], false, nd, errs[(size_t)t]); need[(size_t)t] = nd; });
+        }
+        for (auto &x : th) x.join();
+        for (int t = 0; t < T; t++) if (!errs[(size_t)t].empty()) { err = errs[(size_t)t]; return false; }
+        for (int t = 0; t < T; t++) if (need[(size_t)t]) seq1 = true;
+        if (!seq1) {
+            for (const Counts &z : tc) {
+                for (size_t i = 0; i < z.insertCounts.size(); i++) c.insertCounts[i] += z.insertCounts[i];
+                for (int i = 0; i < c.L; i++) { c.errorPos[i] += z.errorPos[i]; c.inPos[i] += z.inPos[i]; c.inLengths[i] += z.inLengths[i]; c.delPos[i] += z.delPos[i]; c.delLengths[i] += z.delLengths[i]; c.readLengths[i] += z.readLengths[i]; }
+                for (int i = 0; i < 5; i++) { c.baseCounts[i] += z.baseCounts[i]; for (int j = 0; j < 5; j++) c.errorTypes[i][j] += z.errorTypes[i][j]; }
+                c.discardedReads += z.discardedReads; c.uniqueMappedReads += z.uniqueMappedReads;
+            }
         }
     }
+    if (seq1) { bool nd = false; std::string perr; pass1(0, mf.n, c, true, nd, perr); if (!perr.empty()) { err = perr; return false; } }
     Probs p;
     compute_probabilities(c, p);
 
-    // pass 2: gapProbs histogram (computeLikelihood, :1156-1376); only what feeds gapProbCutOff is kept
-    rewind(mf);
+    // ---- pass 2: gapProbs histogram (computeLikelihood, :1156-1376); only what feeds gapProbCutOff is kept.  Ranges start on
+    // a pair boundary where the (qname1, qname2) group changes; every group is counted when the next one starts -- the file's
+    // LAST group never is (the reference only counts a group on seeing its successor, :1290-1330).
     std::vector<long> gapProbs(1000, 0);
-    {
+    auto pass2 = [&](size_t b, size_t e, bool last_range, std::vector<long> &hist, bool &overflow) {
         char l1[kMaxRec], l2[kMaxRec];
         std::vector<long> effLen(c.maxInsertSize, -1);
         auto effective = [&](int ins) -> long {
-            auto calc = [&](int v) { long e = 0; for (int64_t i = 0; i < sc.n(); i++) { long cl = (long)(sc.off[i + 1] - sc.off[i]); if (cl >= v) e += (cl - v + 1); } return e; };
+            auto calc = [&](int v) { long ee = 0; for (int64_t i = 0; i < sc.n(); i++) { long cl = (long)(sc.off[i + 1] - sc.off[i]); if (cl >= v) ee += (cl - v + 1); } return ee; };
             if (ins < 0) return (long)sc.seq.size();
             if (ins >= c.maxInsertSize) return calc(ins);
             if (effLen[ins] == -1) effLen[ins] = calc(ins);
             return effLen[ins];
         };
+        auto count_group = [&](long double sum, long double gapProb, long double &logsum) {
+            if (sum < 1e-320 || std::isnan(sum)) sum = 1e-320;
+            logsum += log10l(sum);
+            int gapIndex = (int)(-log10l(gapProb));
+            gapIndex++;
+            if (gapIndex < 1000 && gapIndex >= 0) hist[gapIndex]++; else hist[999]++;
+        };
         long double sum = 0, logsum = 0, gapProb = 0, tempProb = 0;
         std::string pre1 = "*", pre2 = "*";
-        while (fgets(l1, kMaxRec, mf)) {
-            if (l1[0] == '@') continue;
-            if (!fgets(l2, kMaxRec, mf)) break;
+        size_t pos = b;
+        auto next = [&](char *buf) -> bool {           // next non-header line of the range
+            while (pos < e) { size_t le = line_end(mf, pos); bool hdr = mf.p[pos] == '@'; if (!hdr) copy_line(mf, pos, le, buf); pos = le; if (!hdr) return true; }
+            return false;
+        };
+        while (next(l1)) {
+            if (!next(l2)) break;
             SamCols s1, s2; split_sam(l1, s1); split_sam(l2, s2);
             if (!s1.ok || !s2.ok) continue;
             int insertSize = std::max(s1.tlen, s2.tlen);
@@ -329,20 +440,54 @@ bool build_model(const RunArgs &a, const Scaffold &sc, Model &out, std::string &
                 if (tempProb < prob) { tempProb = prob; gapProb = e2; }
                 sum += prob;
             } else {
-                if (pre1 != "*" && pre2 != "*") {
-                    if (sum < 1e-320 || std::isnan(sum)) sum = 1e-320;
-                    logsum += log10l(sum);
-                    int gapIndex = (int)(-log10l(gapProb));
-                    gapIndex++;
-                    if (gapIndex < 1000 && gapIndex >= 0) gapProbs[gapIndex]++; else gapProbs[999]++;
-                }
+                if (pre1 != "*" && pre2 != "*") count_group(sum, gapProb, logsum);
                 sum = prob; tempProb = prob; gapProb = e2;
             }
             pre1 = s1.qname; pre2 = s2.qname;
-            if (std::isinf(logsum)) { fclose(mf); err = "model likelihood overflow (reference exits here)"; return false; }
+            if (std::isinf(logsum)) { overflow = true; return; }
         }
+        if (!last_range && pre1 != "*" && pre2 != "*") count_group(sum, gapProb, logsum);      // its successor opens the next range
+        if (std::isinf(logsum)) overflow = true;
+    };
+    {
+        bool overflow = false;
+        if (T == 1) pass2(0, mf.n, true, gapProbs, overflow);
+        else {
+            // pair alignment: global index of the first non-header line of each range, then forward to a group change
+            std::vector<size_t> nlines((size_t)T, 0);
+            {   std::vector<std::thread> th;
+                for (int t = 0; t < T; t++) th.emplace_back([&, t] { size_t k = 0; for (size_t pos = cut[(size_t)t]; pos < cut[(size_t)t + 1]; pos = line_end(mf, pos)) if (mf.p[pos] != '@') k++; nlines[(size_t)t] = k; });
+                for (auto &x : th) x.join(); }
+            std::vector<size_t> pc((size_t)T + 1, mf.n);
+            size_t idx = 0;
+            pc[0] = 0;
+            for (int t = 1; t < T; t++) {
+                idx += nlines[(size_t)t - 1];
+                size_t P = cut[(size_t)t];
+                auto skip_hdr = [&](size_t q) { while (q < mf.n && mf.p[q] == '@') q = line_end(mf, q); return q; };
+                P = skip_hdr(P);
+                if (idx & 1) { if (P < mf.n) P = skip_hdr(line_end(mf, P)); }
+                while (P < mf.n) {                       // forward to the first pair that opens a new (qname1, qname2) group
+                    size_t pp;
+                    if (!line_before(mf, P, 2, pp)) break;
+                    size_t pp2 = skip_hdr(line_end(mf, pp));
+                    size_t P2 = skip_hdr(line_end(mf, P));
+                    if (P2 >= mf.n) break;
+                    if (qname_at(mf, pp) == qname_at(mf, P) && qname_at(mf, pp2) == qname_at(mf, P2)) P = skip_hdr(line_end(mf, P2));
+                    else break;
+                }
+                pc[(size_t)t] = std::max(P, pc[(size_t)t - 1]);
+            }
+            std::vector<std::vector<long>> hs((size_t)T, std::vector<long>(1000, 0));
+            std::vector<char> ov((size_t)T, 0);
+            std::vector<std::thread> th;
+            for (int t = 0; t < T; t++) th.emplace_back([&, t] { bool o = false; bool last = true; for (int u = t + 1; u < T; u++) if (pc[(size_t)u] < mf.n) last = false;
+                                                               pass2(pc[(size_t)t], pc[(size_t)t + 1], last, hs[(size_t)t], o); ov[(size_t)t] = o; });
+            for (auto &x : th) x.join();
+            for (int t = 0; t < T; t++) { if (ov[(size_t)t]) overflow = true; for (int i = 0; i < 1000; i++) gapProbs[i] += hs[(size_t)t][i]; }
+        }
+        if (overflow) { err = "model likelihood overflow (reference exits here)"; return false; }
     }
-    fclose(mf);
     long gapProbSum = 0, gapProbCount = 0;
     for (long v : gapProbs) gapProbSum += v;
     int cutoff = 0;

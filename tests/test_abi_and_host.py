@@ -102,3 +102,32 @@ def test_emulation_library_through_the_python_api(tmp_path):
     exp = [ln.split("\t") for ln in util.read(os.path.join(root, "ref", "gapout.txt")).splitlines()]
     assert [int(e[4]) for e in exp] == list(res.filled_len)
     assert [e[5] if len(e) > 5 else "" for e in exp] == res.strings
+
+
+def test_model_build_threads_agree(tmp_path, monkeypatch):
+    """N2: the two passes over myout.sam split over host threads (mmap, ranges cut on pair / qname-group boundaries) give
+    exactly the single-thread model: every accumulated quantity is an integer histogram."""
+    import time
+    c = synth.make_case("mt", 77, "unmapped", [(3000, 30)], coverage=2, n_model_pairs=9000, err=0.01, model_indel_rate=0.08, contig_len=14000)
+    # multi-alignment groups: a few pairs repeated back to back under the same qnames (what `bowtie2 -k` writes)
+    out = []
+    for k in range(0, len(c.myout), 2):
+        out += c.myout[k:k + 2]
+        if (k // 2) % 97 == 0:
+            out += c.myout[k:k + 2] * (1 + (k // 2) % 3)
+    c.myout = out
+    p = synth.write_case(c, str(tmp_path))
+    models, times = [], []
+    for th in ("1", "2", "5", "16"):
+        monkeypatch.setenv("FIGFILL_THREADS", th)
+        t0 = time.time()
+        m = api.model_from_files(p["scf"], p["tmp"], p["myout"], partial_flag=0, unmapped_flag=1, script_itr=1, max_distance=c.max_distance,
+                                 read_length=c.read_len, neg_overlap=30, partial_len=c.partial_len)
+        times.append(time.time() - t0)
+        models.append(m)
+    a = models[0]
+    for b in models[1:]:
+        assert (a.Tmin, a.Tmax, a.cutoff, a.stats) == (b.Tmin, b.Tmax, b.cutoff, b.stats)
+        for x, y in ((a.e, b.e), (a.ins, b.ins), (a.dele, b.dele), (a.T, b.T), (a.insd, b.insd)):
+            assert np.array_equal(x, y)
+    assert a.ins.max() > a.ins.min()            # the indel reads really fed inPosDist
