@@ -30,7 +30,8 @@ def estimate_cost(gap_len: np.ndarray, n_reads: np.ndarray, read_len: int, unmap
     R = np.asarray(n_reads, dtype=np.float64)
     if unmapped:
         cand = np.where(G <= unm_limit // 3, 3.0 * partial_len - 0.3 * G, np.where(G <= unm_limit, 2.0 * G, 1.0))
-        its = np.where(G <= unm_limit, 14.0, 6.0)
+        # placeReads calls per candidate, calibrated on the bench batch (tools/cost_model_check.py, profiles/round2/cost_model_check_*.json)
+        its = np.where(G <= unm_limit // 3, 10.5, np.where(G <= unm_limit, 8.7, 2.0))
         W = np.minimum(G * np.where(G <= unm_limit, 1.5, 1.0) + read_len, 2200.0)
     else:
         cand = np.where(G <= partial_len, 3.0 * partial_len, np.where(G <= 2 * partial_len, 5.0 * G, 1.0))
