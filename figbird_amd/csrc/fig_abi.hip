@@ -34,7 +34,7 @@
 #endif
 // MLE-pass accounting (raw totals incl. discarded speculation; only their ratio is reported): [3] credited, [4] executed
 #define FIG_FLUSH_MLE() do { if (E.mle_alg) atomicAdd(&B.counters[3], E.mle_alg); if (E.lane == 0 && E.mle_exec) atomicAdd(&B.counters[4], E.mle_exec); } while (0)
-struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel; };
+struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel, tiles, tile_step, tile_cols, tiled_max; };
 
 FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
     E.tid = threadIdx.x; E.nt = blockDim.x;
@@ -48,7 +48,16 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.scr = work;
     long long off = 0;
     E.pq_lds = lds_tab; E.w_lds = lds_tab;
-    if (lds_tab) {
+    E.tiles = A.tiles; E.tile_step = A.tile_step; E.tile_cols = A.tile_cols;
+    if (lds_tab && A.tiles > 0) {
+        // LDS-tiled class: LDS = {table tile [4][tile_cols] + Q4 tile, weight rows}; the full table, and the buffers of the
+        // MLE pass (which runs its HBM-table form), stay in the scratch slab
+        E.pq_lds = 0;
+        E.off_pq = 0; E.off_q4 = 8 * A.tile_cols; E.off_w = 9 * A.tile_cols;
+        off = 9LL * A.tile_cols + (long long)A.nteams * A.Wcap;
+        { const long long mle = FIG_TILED_MLE_DOUBLES(A.ncolE, (int)E.nw); if (mle > off && mle <= A.tiled_max) off = mle; }   // as fig_pack sized it
+        E.pq = E.scr.pqg; E.q4 = E.scr.q4g; E.wbuf = E.scr.wg;
+    } else if (lds_tab) {
         E.off_pq = 0; E.off_q4 = 8 * A.ncolE; E.off_w = 9 * A.ncolE;
         off = 9LL * A.ncolE + (long long)A.nteams * A.Wcap;
         E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
@@ -56,7 +65,7 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
         E.off_pq = E.off_q4 = E.off_w = 0;
         E.pq = E.scr.pqg; E.q4 = E.scr.q4g; E.wbuf = E.scr.wg;
     }
-    E.S = (FigState *)(fig_lds + off);
+    E.S = (FigState *)(fig_lds + off); E.lds_tw = (int)off;
     unsigned char *bp = (unsigned char *)(E.S + 1);
     E.gs = bp; bp += ((A.capGl + 7) & ~7);
     E.rb = bp; bp += ((FIG_MAX_READLEN + 8 + 15) & ~15);
@@ -154,7 +163,7 @@ __global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBat
     E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
     E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
     E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.plb = nullptr; E.off_plb = 0; E.pq_lds = 0; E.w_lds = 0;
-    E.off_pq = E.off_q4 = E.off_w = 0;
+    E.off_pq = E.off_q4 = E.off_w = 0; E.tiles = E.tile_step = E.tile_cols = 0; E.lds_tw = 0;
     E.S = (FigState *)fig_lds;
     int4 en = entries[blockIdx.x];
     E.g = &B.gaps[en.x];
@@ -468,6 +477,7 @@ static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     FigKernArgs A;
     A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
     A.q_begin = c.c.q_begin; A.q_end = c.c.q_end; A.qsel = 0;
+    A.tiles = c.c.tiles; A.tile_step = c.c.tile_step; A.tile_cols = c.c.tile_cols; A.tiled_max = c.c.tiled_max;
     return A;
 }
 
@@ -502,6 +512,7 @@ static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevB
 }
 
 static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel = 0) {
+    if (c.c.tiles > 0) return launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);      // LDS-tiled: the LDS code path with a streamed table
     if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, db, stream, kind, blocks, list, n, qsel) : launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);
     return launch_kind<false, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);
 }

@@ -142,7 +142,8 @@ struct FigState {
     int ctl[8];
     // read teams of the unmapped hot path: one read per team, T waves per team
     int tm_lo[16], tm_hi[16], tm_len[16], tm_tis0[16], tm_dir[16];
-    double wv_v[16]; int wv_o[16];   // per-wave partial arg-max
+    int tm_aux[16]; long long tm_woff[16];   // LDS-tiled class: the chunk's read scalars, staged once per chunk
+    double wv_v[32]; int wv_o[32];   // per-wave partial arg-max ([team][wave of the team]; LDS-tiled class: [read of the chunk][wave])
     int mle_next, pad_mn;            // next read of the MLE pass (waves take reads dynamically)
     int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics
     FigLoop L;
@@ -254,6 +255,8 @@ struct FigEng {
     int off_pq, off_q4, off_w;       // offsets (in doubles) from fig_lds when the table / weights live in LDS
     int off_plb;                     // offset (in doubles) of plb from fig_lds (always LDS)
     int pq_lds, w_lds;
+    int lds_tw;                      // doubles of LDS in front of FigState (table/image + weight rows)
+    int tiles, tile_step, tile_cols; // > 0: the table lives in HBM/L2 (pq, q4) and the E-step streams it through an LDS tile at off_pq / off_q4
     double *wbuf;                    // [nteams][Wcap]
     int Wcap, nteams;
     int lane, wave, nw, wsz;         // lane in wave, wave in workgroup, waves per workgroup, lanes per wave

@@ -655,7 +655,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 FigWin w = fig_window_partial(E, PR.pos[pb + p], PR.refpos[pb + p], len, G, gapoffset, 0);
                 FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
                 // reads without N whose placements stay inside the flank window take the table/scalar-load form of the chain
-                bool slow = left < E.xoff;
+                bool slow = left < E.xoff || (LDS && E.tiles > 0);      // LDS-tiled class: the LDS image holds one tile, take the chain on E.pq
                 { bool n = false; for (int j = E.lane; j < len; j += E.wsz) n = n || rbw[j] > 3; slow = slow || fig_wave_any(n); }
                 const FigPQ *PQt = fig_pq_ptr<LDS>(E);
                 fig_cu32p pkr = (fig_cu32p)(fig_uptr(E.B->packed) + fig_u64(PR.woff[pb + p]));
@@ -786,7 +786,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         for (int x = E.tid; x < S.ncols; x += E.nt) E.gs[x] = E.scr.cons[x];
         FIG_SYNC();
         FIG_TICK(E, 6);
-        fig_hot_mle<LDS>(E, gapoffset, 0, G, left, right);
+        fig_mle_dispatch<LDS>(E, gapoffset, 0, G, left, right);
         FIG_TICK(E, 7);
         for (int x = E.tid; x < S.ncols; x += E.nt) for (int j = 0; j < 5; j++) E.scr.ncnt[j * cg + x] = (double)E.scr.nci[j * cg + x];
         // ordered likelihood sum (:3852-3862): the terms are fetched wave-wide (one coalesced load per 64 reads) and then
@@ -990,7 +990,7 @@ FIG_D void fig_finalize(FigEng &E, int gl) {
     if (M.unmapped) {
         if (E.tid == 0) { if (E.B->draw_len) E.B->draw_len[(long long)E.g->gapNo * 2] = G; for (int q = 0; q < 8; q++) S.fin_i[q] = 0; }
         FIG_SYNC();
-        fig_hot_mle<LDS>(E, gapoffset, 1, gl, gsl_left, gsl_right);
+        fig_mle_dispatch<LDS>(E, gapoffset, 1, gl, gsl_left, gsl_right);
         {
             int ncl = gl > cg ? cg : gl;
             for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.cnt[j * cg + x] += (double)E.scr.nci[j * cg + x];

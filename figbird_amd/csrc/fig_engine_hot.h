@@ -466,9 +466,25 @@ FIG_D FigWin fig_window_u(const FigHotU &U, int pos1, int len, int gapoffset) { 
     return w;
 }
 
+// LDS-tiled class: copy columns [x0, x0 + tcols) of the L2-resident table {P,Q}[4][ncolE] + Q4[ncolE] (E.pq, E.q4) into
+// the LDS image {P,Q}[4][tcols] + Q4[tcols] at off_pq / off_q4.  All lanes; the caller brackets it with barriers.
+// Columns past the table's end are left as they are: no placement of a valid lane reaches them.
+FIG_D void fig_tile_copy(FigEng &E, int x0, int tcols) {
+    const int ncolE = fig_u(E.ncolE);
+    const FigPQ *src = fig_uptr(E.pq) + x0; const double *sq = fig_uptr(E.q4) + x0;
+    FigPQ *dst = (FigPQ *)(fig_lds + fig_u(E.off_pq)); double *dq = fig_lds + fig_u(E.off_q4);
+    int n = ncolE - x0; if (n > tcols) n = tcols;
+    // the five loads of a column are issued together (the copy is latency-bound: one L2 round trip per loop trip)
+    for (int x = E.tid; x < n; x += E.nt) {
+        const FigPQ v0 = src[x], v1 = src[ncolE + x], v2 = src[2 * ncolE + x], v3 = src[3 * ncolE + x];
+        const double q = sq[x];
+        dst[x] = v0; dst[tcols + x] = v1; dst[2 * tcols + x] = v2; dst[3 * tcols + x] = v3; dq[x] = q;
+    }
+}
+
 // ---------------------------------------------------------------------------------------
 // E-step over all unmapped reads of the gap (Figbird.cpp:3530-3689).  CPL = columns per lane.
-template <bool LDS, int CPL>
+template <bool LDS, int CPL, bool TILED>
 FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     FigState &S = *E.S;
     const FigHotU U = fig_hot_uniforms(E);
@@ -483,6 +499,10 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid;
     const int team = wave / T, wit = wave - team * T;
     const bool clipped = left < xoff;              // some placements start left of the window (gap near the contig start)
+    // LDS-tiled class (table too wide for LDS): PQ/Q4 above point at an image of tile_cols columns, refilled per tile
+    const int ntl = TILED ? fig_u(E.tiles) : 1, tstep = TILED ? fig_u(E.tile_step) : 0;
+    const int pstride = TILED ? fig_u(E.tile_cols) : ncolE;      // column stride of the image the chains read
+    const int Tm = TILED ? U.nw : T;                             // arg-max slots per read (S.wv_*)
     // Column pass: wave w owns base c = w & 3 and CPL consecutive 64-column tiles starting at tile (w >> 2) * CPL,
     // one register accumulator per tile for the whole E-step.  All tiles of a wave walk the same position list
     // (that base's positions in the read, four per staged dword), so the list decode is shared and the CPL add
@@ -502,128 +522,214 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
 
     FIG_T0(E);
     for (int c0 = 0; c0 < nU; c0 += nteams) {
-        // ---- phase A: lanes = placements
-        int r = c0 + team;
-        FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
-        if (team < nteams && r < nU) {
-            FIG_T0(E);
-            FigReadS rs = fig_read_scalars(U, ub + r);
-            FigWin w = fig_window_u(U, rs.pos, rs.len, gapoffset);
-            if (wit == 0 && lane == 0) { S.tm_lo[team] = w.lo; S.tm_hi[team] = w.hi; S.tm_len[team] = rs.len; }
-            fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
-            int nw2 = (rs.len + 15) >> 4;
-            // stage {counts, position lists} of this read for the column pass: one dword per lane, stored below
-            uint32_t plv = 0;
-            if (CPL > 0 && wit == 0) { const int ndw = 2 + ((rs.len + 3) >> 2) + 4; if (lane < ndw) plv = pk[nw2 + ((rs.len + 31) >> 5) + lane]; }
-            fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
-            // weight row covers every placement offset o in [-(L-1), G-1] at index o+(L-1); offsets outside the
-            // insert-size window hold 0.0 so that the column pass needs no window test (x + 0.0 == x exactly)
-            double *wrow = W + (long long)team * Wcap + (U.L - 1);
-            for (int i = -(U.L - 1) + wit * U.wsz + lane; i < G; i += T * U.wsz) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
-            unsigned long long nplace = 0, nadd = 0;
-            // does the read contain an N?  (then the generic chain handles it)
-            const bool hasN = rs.hasN != 0;
-            const int stride = T * U.wsz;
-            int o = w.lo + wit * U.wsz + lane;
-            if (!hasN && !clipped) {
-                // Wave-uniform rounds.  Full team rounds (2*stride placements: every wave of the team has both halves of
-                // its pair), then the tail of < 2*stride placements is cut into T equal stretches, one per wave, so the
-                // waves of a team finish together: a stretch of more than one wave width runs as a pair round whose second
-                // half is masked (those lanes read inside the LDS image and are ignored), a shorter one as a single round.
-                const int Wn = w.hi - w.lo + 1;
-                const int nfull = Wn > 0 ? Wn / (2 * stride) : 0;
-                // insert-size terms of the next round are fetched before the current round's chains (their latency would
-                // otherwise sit in front of the first multiply)
-                double pa_n = 0, pb_n = 0;
-                if (nfull > 0) { const int oa0 = w.lo + wit * U.wsz + lane; pa_n = U.insd[w.tis0 + w.dir * oa0]; pb_n = U.insd[w.tis0 + w.dir * (oa0 + stride)]; }
-                FIG_TICK(E, 22);
-                for (int k = 0; k < nfull; k++) {
+        if (!TILED) {
+            // ---- phase A: lanes = placements
+            int r = c0 + team;
+            FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+            if (team < nteams && r < nU) {
+                FIG_T0(E);
+                FigReadS rs = fig_read_scalars(U, ub + r);
+                FigWin w = fig_window_u(U, rs.pos, rs.len, gapoffset);
+                if (wit == 0 && lane == 0) { S.tm_lo[team] = w.lo; S.tm_hi[team] = w.hi; S.tm_len[team] = rs.len; }
+                fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+                int nw2 = (rs.len + 15) >> 4;
+                // stage {counts, position lists} of this read for the column pass: one dword per lane, stored below
+                uint32_t plv = 0;
+                if (CPL > 0 && wit == 0) { const int ndw = 2 + ((rs.len + 3) >> 2) + 4; if (lane < ndw) plv = pk[nw2 + ((rs.len + 31) >> 5) + lane]; }
+                fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
+                // weight row covers every placement offset o in [-(L-1), G-1] at index o+(L-1); offsets outside the
+                // insert-size window hold 0.0 so that the column pass needs no window test (x + 0.0 == x exactly)
+                double *wrow = W + (long long)team * Wcap + (U.L - 1);
+                for (int i = -(U.L - 1) + wit * U.wsz + lane; i < G; i += T * U.wsz) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
+                unsigned long long nplace = 0, nadd = 0;
+                // does the read contain an N?  (then the generic chain handles it)
+                const bool hasN = rs.hasN != 0;
+                const int stride = T * U.wsz;
+                int o = w.lo + wit * U.wsz + lane;
+                if (!hasN && !clipped) {
+                    // Wave-uniform rounds.  Full team rounds (2*stride placements: every wave of the team has both halves of
+                    // its pair), then the tail of < 2*stride placements is cut into T equal stretches, one per wave, so the
+                    // waves of a team finish together: a stretch of more than one wave width runs as a pair round whose second
+                    // half is masked (those lanes read inside the LDS image and are ignored), a shorter one as a single round.
+                    const int Wn = w.hi - w.lo + 1;
+                    const int nfull = Wn > 0 ? Wn / (2 * stride) : 0;
+                    // insert-size terms of the next round are fetched before the current round's chains (their latency would
+                    // otherwise sit in front of the first multiply)
+                    double pa_n = 0, pb_n = 0;
+                    if (nfull > 0) { const int oa0 = w.lo + wit * U.wsz + lane; pa_n = U.insd[w.tis0 + w.dir * oa0]; pb_n = U.insd[w.tis0 + w.dir * (oa0 + stride)]; }
+                    FIG_TICK(E, 22);
+                    for (int k = 0; k < nfull; k++) {
 #ifndef FIG_EMU
-                    // 8-wave workgroups put waves w and w+4 on one SIMD and the arbiter serves the older one first; taking
-                    // turns at the higher priority, round by round, lets the two finish the phase together
-                    if (U.nw == 8) { if ((k + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+                        // 8-wave workgroups put waves w and w+4 on one SIMD and the arbiter serves the older one first; taking
+                        // turns at the higher priority, round by round, lets the two finish the phase together
+                        if (U.nw == 8) { if ((k + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
 #endif
-                    const int oa = w.lo + k * 2 * stride + wit * U.wsz + lane, ob = oa + stride;
-                    double pa = pa_n, pb = pb_n;
-                    if (k + 1 < nfull) { pa_n = U.insd[w.tis0 + w.dir * (oa + 2 * stride)]; pb_n = U.insd[w.tis0 + w.dir * (ob + 2 * stride)]; }
-                    FIG_T0(E);
-#ifdef FIG_EMU
-                    fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
-#else
-                    if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
-                    else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
-                    else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
-#endif
-                    FIG_TICK(E, 9);
-                    const double ta = fig_log10(pa), tb = fig_log10(pb);
-                    if (ta > best.v) { best.v = ta; best.o = oa; }
-                    if (tb > best.v) { best.v = tb; best.o = ob; }
-                    wrow[oa] = fig_exp(0.5 * ta);
-                    wrow[ob] = fig_exp(0.5 * tb);
-                    FIG_TICK(E, 10);
-                    nplace += 2; nadd += fig_ovl(oa, rs.len, G) + fig_ovl(ob, rs.len, G);
-                }
-#ifndef FIG_EMU
-                if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
-#endif
-                {
-                    const int tbase = w.lo + nfull * 2 * stride;
-                    const int nt = w.hi - tbase + 1;                            // 0 .. 2*stride-1
-                    const int per_w = (nt + T - 1) / T;
-                    const int start = tbase + wit * per_w;
-                    int m = w.hi - start + 1; if (m > per_w) m = per_w;        // this wave's stretch: [start, start + m)
-                    if (m > U.wsz) {
-                        const int oa = start + lane, ob = oa + U.wsz;
-                        const bool vb = ob < start + m;
-                        double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * (vb ? ob : oa)];
+                        const int oa = w.lo + k * 2 * stride + wit * U.wsz + lane, ob = oa + stride;
+                        double pa = pa_n, pb = pb_n;
+                        if (k + 1 < nfull) { pa_n = U.insd[w.tis0 + w.dir * (oa + 2 * stride)]; pb_n = U.insd[w.tis0 + w.dir * (ob + 2 * stride)]; }
                         FIG_T0(E);
 #ifdef FIG_EMU
-                        fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
+                        fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
 #else
-                        fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+                        if (T == 1) fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+                        else if (T == 2) fig_hot_chain_e2<LDS, 128>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+                        else fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, ob + xoff, pa, pb);
 #endif
                         FIG_TICK(E, 9);
                         const double ta = fig_log10(pa), tb = fig_log10(pb);
-                        const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
                         if (ta > best.v) { best.v = ta; best.o = oa; }
-                        wrow[oa] = wa;
-                        if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
+                        if (tb > best.v) { best.v = tb; best.o = ob; }
+                        wrow[oa] = fig_exp(0.5 * ta);
+                        wrow[ob] = fig_exp(0.5 * tb);
                         FIG_TICK(E, 10);
-                        nplace += vb ? 2 : 1; nadd += fig_ovl(oa, rs.len, G) + (vb ? fig_ovl(ob, rs.len, G) : 0);
-                    } else if (m > 0) {
-                        const int oa = start + lane;
-                        const bool va = lane < m;
-                        const int ca = va ? oa : start;
-                        double pa = U.insd[w.tis0 + w.dir * ca];
-                        FIG_T0(E);
-                        fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
-                        const double ta = fig_log10(pa);
-                        const double wa = fig_exp(0.5 * ta);
-                        if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; nadd += fig_ovl(oa, rs.len, G); }
-                        FIG_TICK(E, 23);
+                        nplace += 2; nadd += fig_ovl(oa, rs.len, G) + fig_ovl(ob, rs.len, G);
                     }
+#ifndef FIG_EMU
+                    if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
+#endif
+                    {
+                        const int tbase = w.lo + nfull * 2 * stride;
+                        const int nt = w.hi - tbase + 1;                            // 0 .. 2*stride-1
+                        const int per_w = (nt + T - 1) / T;
+                        const int start = tbase + wit * per_w;
+                        int m = w.hi - start + 1; if (m > per_w) m = per_w;        // this wave's stretch: [start, start + m)
+                        if (m > U.wsz) {
+                            const int oa = start + lane, ob = oa + U.wsz;
+                            const bool vb = ob < start + m;
+                            double pa = U.insd[w.tis0 + w.dir * oa], pb = U.insd[w.tis0 + w.dir * (vb ? ob : oa)];
+                            FIG_T0(E);
+#ifdef FIG_EMU
+                            fig_hot_chain_e2<LDS, 0>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, (vb ? ob : oa) + xoff, pa, pb);
+#else
+                            fig_hot_chain_e2<LDS, 64>(PQ, ncolE, pk, nw2, kt, rs.len, oa + xoff, 0, pa, pb);
+#endif
+                            FIG_TICK(E, 9);
+                            const double ta = fig_log10(pa), tb = fig_log10(pb);
+                            const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
+                            if (ta > best.v) { best.v = ta; best.o = oa; }
+                            wrow[oa] = wa;
+                            if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; }
+                            FIG_TICK(E, 10);
+                            nplace += vb ? 2 : 1; nadd += fig_ovl(oa, rs.len, G) + (vb ? fig_ovl(ob, rs.len, G) : 0);
+                        } else if (m > 0) {
+                            const int oa = start + lane;
+                            const bool va = lane < m;
+                            const int ca = va ? oa : start;
+                            double pa = U.insd[w.tis0 + w.dir * ca];
+                            FIG_T0(E);
+                            fig_hot_chain_e1<LDS>(PQ, ncolE, pk, kt, rs.len, ca + xoff, pa);
+                            const double ta = fig_log10(pa);
+                            const double wa = fig_exp(0.5 * ta);
+                            if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; nadd += fig_ovl(oa, rs.len, G); }
+                            FIG_TICK(E, 23);
+                        }
+                    }
+                    o = w.hi + 1;
                 }
-                o = w.hi + 1;
+                { FIG_T0(E);
+                for (; o <= w.hi; o += stride) {
+                    int tis = w.tis0 + w.dir * o;
+                    int jstart = clipped ? (-left - o > 0 ? -left - o : 0) : 0;
+                    double p = fig_hot_chain_e<LDS>(PQ, Q4, ncolE, pk, nw2, kt, rs.len, jstart, clipped, o + xoff, U.insd[tis]);
+                    double t = fig_log10(p);
+                    if (t > best.v) { best.v = t; best.o = o; }
+                    wrow[o] = fig_exp(0.5 * t);
+                    nplace++; nadd += fig_ovl(o, rs.len, G);
+                }
+                FIG_TICK(E, 24); }
+                fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
+                // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do; the
+                // offset of (one of) the maximal placements is kept as a pruning hint for the MLE pass of this placeReads call
+                { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
+                  const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
+                  const int ao = am ? fig_lane_read_i32(best.o, fig_ctz64(am)) : FIG_NOPOS;
+                  if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; } }
+                if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;
             }
-            { FIG_T0(E);
-            for (; o <= w.hi; o += stride) {
-                int tis = w.tis0 + w.dir * o;
-                int jstart = clipped ? (-left - o > 0 ? -left - o : 0) : 0;
-                double p = fig_hot_chain_e<LDS>(PQ, Q4, ncolE, pk, nw2, kt, rs.len, jstart, clipped, o + xoff, U.insd[tis]);
-                double t = fig_log10(p);
-                if (t > best.v) { best.v = t; best.o = o; }
-                wrow[o] = fig_exp(0.5 * t);
-                nplace++; nadd += fig_ovl(o, rs.len, G);
+        } else {
+            // ---- phase A, LDS-tiled class: the table is streamed through the LDS image one column tile at a time.  A placement
+            // belongs to the tile that holds its first column (tiles overlap by a read length, so it reads inside the image).
+            // Per tile, the chunk's reads are cut into units of 2 x 64 consecutive placements and the units are dealt round-robin
+            // over ALL waves, so that the waves reach the tile's barrier together whatever the reads' windows look like.
+            const int nrd = nU - c0 < nteams ? nU - c0 : nteams;
+            for (int t = 0; t < nrd; t++) {
+                const FigReadS rs = fig_read_scalars(U, ub + c0 + t);
+                const FigWin w = fig_window_u(U, rs.pos, rs.len, gapoffset);
+                if (tid == 0) { S.tm_lo[t] = w.lo; S.tm_hi[t] = w.hi; S.tm_len[t] = rs.len; S.tm_tis0[t] = w.tis0; S.tm_dir[t] = w.dir;
+                                S.tm_aux[t] = rs.rev | (rs.hasN << 1); S.tm_woff[t] = rs.woff; }
+                if (lane == 0) { S.wv_v[t * U.nw + wave] = -FIG_DBL_MAX; S.wv_o[t * U.nw + wave] = FIG_NOPOS; }
+                double *wrow = W + (long long)t * Wcap + (U.L - 1);
+                for (int i = -(U.L - 1) + tid; i < G; i += U.nt) if (i < w.lo || i > w.hi) wrow[i] = 0.0;
+                if (CPL > 0 && wave == t) {                     // stage {counts, position lists} for the column pass (t < nteams <= nw)
+                    fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+                    const int ndw = 2 + ((rs.len + 3) >> 2) + 4;
+                    plb[t * 64 + lane] = lane < ndw ? pk[((rs.len + 15) >> 4) + ((rs.len + 31) >> 5) + lane] : 0u;
+                }
             }
-            FIG_TICK(E, 24); }
-            fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
-            // only the value and "was there any placement" are used downstream (:3680-3688), so a plain maximum will do; the
-            // offset of (one of) the maximal placements is kept as a pruning hint for the MLE pass of this placeReads call
-            { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
-              const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
-              const int ao = am ? fig_lane_read_i32(best.o, fig_ctz64(am)) : FIG_NOPOS;
-              if (lane == 0) { S.wv_v[wave] = bv; S.wv_o[wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; } }
-            if (CPL > 0 && wit == 0) plb[team * 64 + lane] = plv;
+            for (int tl = 0; tl < ntl; tl++) {
+                const int x0 = tl * tstep;
+                FIG_SYNC();                                   // the chains of the previous tile are done with the image
+                fig_tile_copy(E, x0, pstride);
+                FIG_SYNC();
+                const int xs = xoff - x0;                     // image column of placement offset 0
+                int ubase = 0;
+                for (int t = 0; t < nrd; t++) {
+                    // the read's scalars come from the copy staged in LDS (a scalar-load round trip per read and tile otherwise)
+                    FigReadS rs; FigWin w;
+                    w.lo = fig_u(S.tm_lo[t]); w.hi = fig_u(S.tm_hi[t]); w.tis0 = fig_u(S.tm_tis0[t]); w.dir = fig_u(S.tm_dir[t]);
+                    rs.len = fig_u(S.tm_len[t]); { const int a = fig_u(S.tm_aux[t]); rs.rev = a & 1; rs.hasN = (a >> 1) & 1; }
+                    rs.pos = 0; rs.woff = fig_u64(S.tm_woff[t]);
+                    int lo_t = w.lo, hi_t = w.hi;
+                    if (tl > 0 && x0 - xoff > lo_t) lo_t = x0 - xoff;
+                    if (tl + 1 < ntl && x0 + tstep - 1 - xoff < hi_t) hi_t = x0 + tstep - 1 - xoff;
+                    if (hi_t < lo_t) continue;
+                    const int usz = 2 * U.wsz;
+                    const int nun = (hi_t - lo_t + usz) / usz;
+                    int k = (wave - ubase % U.nw + U.nw) % U.nw;
+                    ubase += nun;
+                    if (k >= nun) continue;
+                    fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+                    const int nw2 = (rs.len + 15) >> 4;
+                    fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
+                    double *wrow = W + (long long)t * Wcap + (U.L - 1);
+                    const bool generic = rs.hasN != 0 || clipped;
+                    FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+                    unsigned long long nplace = 0, nadd = 0;
+                    for (; k < nun; k += U.nw) {
+                        const int base = lo_t + k * usz;
+                        const int oa = base + lane, ob = oa + U.wsz;
+                        const bool va = oa <= hi_t, vb = ob <= hi_t;
+                        const int ca = va ? oa : base, cb = vb ? ob : base;
+                        double pa = U.insd[w.tis0 + w.dir * ca], pb = U.insd[w.tis0 + w.dir * cb];
+                        FIG_T0(E);
+                        if (!generic) {
+#ifdef FIG_EMU
+                            fig_hot_chain_e2<LDS, 0>(PQ, pstride, pk, nw2, kt, rs.len, ca + xs, cb + xs, pa, pb);
+#else
+                            fig_hot_chain_e2<LDS, 64>(PQ, pstride, pk, nw2, kt, rs.len, base + lane + xs, 0, pa, pb);
+#endif
+                        } else {
+                            if (va) pa = fig_hot_chain_e<LDS>(PQ, Q4, pstride, pk, nw2, kt, rs.len, clipped ? (-left - oa > 0 ? -left - oa : 0) : 0, clipped, oa + xs, pa);
+                            if (vb) pb = fig_hot_chain_e<LDS>(PQ, Q4, pstride, pk, nw2, kt, rs.len, clipped ? (-left - ob > 0 ? -left - ob : 0) : 0, clipped, ob + xs, pb);
+                        }
+                        FIG_TICK(E, 9);
+                        const double ta = fig_log10(pa), tb = fig_log10(pb);
+                        const double wa = fig_exp(0.5 * ta), wb = fig_exp(0.5 * tb);
+                        if (va) { if (ta > best.v) { best.v = ta; best.o = oa; } wrow[oa] = wa; nplace++; nadd += fig_ovl(oa, rs.len, G); }
+                        if (vb) { if (tb > best.v) { best.v = tb; best.o = ob; } wrow[ob] = wb; nplace++; nadd += fig_ovl(ob, rs.len, G); }
+                        FIG_TICK(E, 10);
+                    }
+                    fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
+                    // fold this wave's arg-max of read t into its own slot (no other wave writes it)
+                    { const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
+                      const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
+                      if (am) {
+                          const int ao = fig_lane_read_i32(best.o, fig_ctz64(am));
+                          const int sl = t * U.nw + wave;
+                          if (lane == 0 && (S.wv_o[sl] == FIG_NOPOS || bv > S.wv_v[sl])) { S.wv_v[sl] = bv; S.wv_o[sl] = ao; }
+                      } }
+                }
+            }
         }
         FIG_TICK(E, 11);
         FIG_SYNC();
@@ -631,7 +737,7 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
         // ---- per-read bookkeeping (:3680-3688)
         if (tid < nteams && c0 + tid < nU) {
             FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
-            for (int k = 0; k < T; k++) { FigBest y; y.v = S.wv_v[tid * T + k]; y.o = S.wv_o[tid * T + k]; b = fig_best_merge(b, y); }
+            for (int k = 0; k < Tm; k++) { FigBest y; y.v = S.wv_v[tid * Tm + k]; y.o = S.wv_o[tid * Tm + k]; b = fig_best_merge(b, y); }
             if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + tid] = b.v;
             else { E.scr.maxlv[c0 + tid] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
             E.scr.hint_e[c0 + tid] = b.o;
@@ -741,24 +847,32 @@ FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
 template <bool LDS>
 FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
 #ifdef FIG_EMU
-    fig_hot_estep<LDS, 0>(E, gapoffset);
+    if (LDS && E.tiles > 0) fig_hot_estep<LDS, 0, true>(E, gapoffset);
+    else fig_hot_estep<LDS, 0, false>(E, gapoffset);
 #else
     const int ntiles = (E.S->G + E.wsz - 1) / E.wsz;
     const int nsub = E.nw >> 2;                          // waves per base (workgroups are 4 or 8 waves)
     const int cpl = nsub > 0 ? (ntiles + nsub - 1) / nsub : 99;      // tiles per wave
+    if (LDS && E.tiles > 0) {                            // LDS-tiled class: wide gaps only, but a candidate can be much shorter than the class
+        if (cpl <= 8) fig_hot_estep<LDS, 8, true>(E, gapoffset);
+        else if (cpl <= 12) fig_hot_estep<LDS, 12, true>(E, gapoffset);
+        else if (cpl <= 16) fig_hot_estep<LDS, 16, true>(E, gapoffset);
+        else fig_hot_estep<LDS, 0, true>(E, gapoffset);
+        return;
+    }
     switch (cpl) {
-        case 1: fig_hot_estep<LDS, 1>(E, gapoffset); break;
-        case 2: fig_hot_estep<LDS, 2>(E, gapoffset); break;
-        case 3: fig_hot_estep<LDS, 3>(E, gapoffset); break;
-        case 4: fig_hot_estep<LDS, 4>(E, gapoffset); break;
-        case 5: fig_hot_estep<LDS, 5>(E, gapoffset); break;
-        case 6: fig_hot_estep<LDS, 6>(E, gapoffset); break;
-        case 7: fig_hot_estep<LDS, 7>(E, gapoffset); break;
-        case 8: fig_hot_estep<LDS, 8>(E, gapoffset); break;
-        case 9: case 10: fig_hot_estep<LDS, 10>(E, gapoffset); break;
-        case 11: case 12: fig_hot_estep<LDS, 12>(E, gapoffset); break;
-        case 13: case 14: case 15: case 16: fig_hot_estep<LDS, 16>(E, gapoffset); break;
-        default: fig_hot_estep<LDS, 0>(E, gapoffset); break;
+        case 1: fig_hot_estep<LDS, 1, false>(E, gapoffset); break;
+        case 2: fig_hot_estep<LDS, 2, false>(E, gapoffset); break;
+        case 3: fig_hot_estep<LDS, 3, false>(E, gapoffset); break;
+        case 4: fig_hot_estep<LDS, 4, false>(E, gapoffset); break;
+        case 5: fig_hot_estep<LDS, 5, false>(E, gapoffset); break;
+        case 6: fig_hot_estep<LDS, 6, false>(E, gapoffset); break;
+        case 7: fig_hot_estep<LDS, 7, false>(E, gapoffset); break;
+        case 8: fig_hot_estep<LDS, 8, false>(E, gapoffset); break;
+        case 9: case 10: fig_hot_estep<LDS, 10, false>(E, gapoffset); break;
+        case 11: case 12: fig_hot_estep<LDS, 12, false>(E, gapoffset); break;
+        case 13: case 14: case 15: case 16: fig_hot_estep<LDS, 16, false>(E, gapoffset); break;
+        default: fig_hot_estep<LDS, 0, false>(E, gapoffset); break;
     }
 #endif
 }
@@ -768,7 +882,6 @@ FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
 // fbuf, and then every lane multiplies them up in the reference's order j = 0, 1, ...; so the result is bit-identical
 // to the lane-per-placement chain but costs ~len dependent multiplies instead of a whole 128-placement round.
 // fbuf: >= len doubles private to the wave (LDS ops of one wave execute in order, so no barrier is needed).
-#define FIG_MLE_FB 208
 // What a lane needs of the read for its factors j = lane, lane + wsz, ...: loaded once per read with vector loads
 // (their latency hides behind the first chain blocks), then reused by every serial evaluation of that read.
 struct FigSerLane { int b[4]; double m3[4], e[4]; };
@@ -1392,6 +1505,22 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
         for (int x = E.tid; x < ncl; x += E.nt) for (int j = 0; j < 5; j++) E.scr.nci[j * cg + x] = nl[j * nst + x];
         FIG_SYNC();
     }
+}
+
+// The MLE pass behind its class's memory form.  LDS-tiled class: the E-step's image and weight rows are idle now, and the
+// MLE table needs 5 doubles per column where {P,Q}+Q4 needed 9, so the pass runs its LDS form over the whole column range
+// whenever C[5][ncolE] + the per-column records + its buffers fit the area in front of FigState (the packer sized the
+// workgroup's LDS for it when it could); otherwise it runs on the table in the scratch slab.
+template <bool LDS>
+FIG_D void fig_mle_dispatch(FigEng &E, int gapoffset, int mode, int gl, int wl, int wr) {
+    if (!(LDS && E.tiles > 0)) { fig_hot_mle<LDS>(E, gapoffset, mode, gl, wl, wr); return; }
+    if (FIG_TILED_MLE_DOUBLES(E.ncolE, E.nw) > E.lds_tw) { fig_hot_mle<false>(E, gapoffset, mode, gl, wl, wr); return; }
+    FigPQ *const pq_keep = E.pq; double *const q4_keep = E.q4; double *const w_keep = E.wbuf;
+    const int off_w_keep = E.off_w, nteams_keep = E.nteams, Wcap_keep = E.Wcap;
+    E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = nullptr; E.off_w = E.off_pq + 7 * E.ncolE; E.wbuf = fig_lds + E.off_w;
+    E.nteams = 1; E.Wcap = E.lds_tw - 7 * E.ncolE;              // "one weight row" = everything behind the records
+    fig_hot_mle<true>(E, gapoffset, mode, gl, wl, wr);
+    E.pq = pq_keep; E.q4 = q4_keep; E.wbuf = w_keep; E.off_w = off_w_keep; E.nteams = nteams_keep; E.Wcap = Wcap_keep;
 }
 
 #endif

@@ -85,7 +85,8 @@ static inline double fig_model_fmm(const fig_model *m) {
     return f < 1.0 ? f : 1.0;
 }
 
-struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end; };
+struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end;
+                        int tiles, tile_step, tile_cols, tiled_max; };     // tiled_max: doubles of LDS the table/weight area may grow to      // tiles > 0: table in HBM/L2, streamed through an LDS tile per chunk (fig_hot_estep)
 
 struct FigPacked {
     std::vector<FigDevGap> gaps;
@@ -262,13 +263,34 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             size_t need = fixed + sizeof(double) * ((size_t)9 * c.ncolE + (size_t)nt_ * c.Wcap);
             if (need <= LDS_MAX) { c.lds_tab = true; c.nteams = nt_; c.lds = need; break; }
         }
-        if (!c.lds_tab) { c.lds = fixed + 64; c.nt = 512; c.nteams = 8; }
+        c.tiles = 0; c.tile_step = 0; c.tile_cols = 0; c.tiled_max = 0;
+        if (!c.lds_tab) {
+            c.lds = fixed + 64; c.nt = 512; c.nteams = 8;
+            // LDS-tiled form: the weight rows stay in LDS and the E-step streams the table through one LDS tile of columns at a
+            // time (tiles overlap by a read length: a placement belongs to the tile that holds its first column).  Most rows first,
+            // then fewest tiles.
+            bool found = false;
+            for (int nt_ = 4; nt_ >= 1 && !found; nt_ >>= 1)
+                for (int ntl = 2; ntl <= 8 && !found; ntl++) {
+                    int step = ((c.ncolE + ntl - 1) / ntl + 7) & ~7;
+                    int tcols = (step + m->max_read_length + 8 + 7) & ~7;
+                    size_t need = fixed + sizeof(double) * ((size_t)9 * tcols + (size_t)nt_ * c.Wcap);
+                    if (need <= LDS_MAX) { found = true; c.tiles = ntl; c.tile_step = step; c.tile_cols = tcols; c.nteams = nt_; c.lds = need; }
+                }
+            if (found) {
+                // the MLE pass of this class runs its LDS form when {C[5], packed-consensus records} of all columns + its
+                // buffers fit (fig_tiled_mle_doubles); the area in front of FigState is the larger of the two layouts
+                c.tiled_max = (int)((LDS_MAX - fixed) / sizeof(double));
+                const long long mle = FIG_TILED_MLE_DOUBLES(c.ncolE, c.nt / 64);
+                if (mle <= c.tiled_max && fixed + sizeof(double) * (size_t)mle > c.lds) c.lds = fixed + sizeof(double) * (size_t)mle;
+            }
+        }
         c.q_begin = (int)K.order.size();
         for (int32_t id : ids) { K.gaps[id].cls = (int)K.classes.size(); K.order.push_back(id); }
         c.q_end = (int)K.order.size();
         K.classes.push_back(c);
         K.capE = std::max(K.capE, c.ncolE);
-        K.capW = std::max(K.capW, c.nteams * c.Wcap + 1024);   // + slack: the column pass reads up to 2 tiles past a row's end
+        K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
     }
     return FIG_OK;
 }

@@ -14,6 +14,10 @@
 #define FIG_MAX_GAP 100000           // MAX_GAP, Figbird.cpp:30
 #define FIG_FLANK 208                // flank window kept per side: >= max(read length, side_limit=30)
 #define FIG_DBL_MAX 1.7976931348623157e308
+#define FIG_MLE_FB 208               // doubles of the per-wave factor buffer of the MLE pass (>= FIG_MAX_READLEN)
+// LDS-tiled class: doubles of LDS the MLE pass needs to run its LDS form over all ncolE columns: C[5][ncolE], one 16-byte
+// packed-consensus record per column, the per-wave factor buffers, the packed consensus words (kc, kn) and slack
+#define FIG_TILED_MLE_DOUBLES(ncolE, nw) (7LL * (ncolE) + (long long)(nw) * FIG_MLE_FB + ((ncolE) + 15) / 16 + 16 + 8)
 
 struct FigDevModel {
     int32_t L;                       // maxReadLength

@@ -125,7 +125,16 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     for (const FigLaunchClass &c : K.classes) {
         // one emulated lane = one wave of width 1; the class's team count is kept so the chunking logic runs
         int nteams = 1;
-        std::vector<double> lds((size_t)(9LL * c.ncolE + (long long)nteams * c.Wcap) + (sizeof(FigState) + c.capGl + FIG_MAX_READLEN + 64 + FIG_PLB_BYTES) / 8 + 8, 0.0);
+        // LDS-tiled form of a class (fig_pack.h): what the packer chose, or forced on every class by FIG_EMU_TILES=<n> so that the
+        // tile logic of the E-step is exercised on small gaps too
+        int tiles = c.tiles, tile_step = c.tile_step, tile_cols = c.tile_cols;
+        if (const char *ft = getenv("FIG_EMU_TILES")) {
+            tiles = atoi(ft);
+            if (tiles > 0) { tile_step = ((c.ncolE + tiles - 1) / tiles + 7) & ~7; tile_cols = (tile_step + M.L + 8 + 7) & ~7; }
+            fprintf(stderr, "[figemu] class ncolE=%d: LDS-tiled E-step forced, tiles=%d step=%d cols=%d\n", c.ncolE, tiles, tile_step, tile_cols);
+        }
+        const long long tabc = tiles > 0 && tile_cols > c.ncolE ? tile_cols : c.ncolE;
+        std::vector<double> lds((size_t)(9LL * tabc + (long long)nteams * c.Wcap) + (sizeof(FigState) + c.capGl + FIG_MAX_READLEN + 64 + FIG_PLB_BYTES) / 8 + 8, 0.0);
         fig_lds = lds.data();
         FigEng E;
         E.tid = 0; E.nt = 1; E.lane = 0; E.wave = 0; E.nw = 1; E.wsz = 1;
@@ -135,7 +144,13 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         E.pq_lds = 1; E.w_lds = 1;
         E.off_pq = 0; E.off_q4 = 8 * c.ncolE; E.off_w = 9 * c.ncolE;
         E.pq = (FigPQ *)(fig_lds + E.off_pq); E.q4 = fig_lds + E.off_q4; E.wbuf = fig_lds + E.off_w;
-        E.S = (FigState *)(fig_lds + 9LL * c.ncolE + (long long)nteams * c.Wcap);
+        E.tiles = tiles; E.tile_step = tile_step; E.tile_cols = tile_cols;
+        if (tiles > 0) {      // as fig_eng_init does: image of one tile + the weight rows in "LDS", table and MLE buffers in the slab
+            E.pq_lds = 0;
+            E.off_q4 = 8 * tile_cols; E.off_w = 9 * tile_cols;
+            E.pq = E.scr.pqg; E.q4 = E.scr.q4g; E.wbuf = E.scr.wg;
+        }
+        E.S = (FigState *)(fig_lds + 9LL * tabc + (long long)nteams * c.Wcap); E.lds_tw = (int)(9LL * tabc + (long long)nteams * c.Wcap);
         unsigned char *bp = (unsigned char *)(E.S + 1);
         E.gs = bp; bp += ((c.capGl + 7) & ~7); E.rb = bp; bp += ((FIG_MAX_READLEN + 8 + 15) & ~15); E.plb = (uint32_t *)bp; E.off_plb = 0;
         E.kt_fwd = M.ome; E.kt_rev = M.ome + 2 * M.L; E.mt_fwd = M.ome + 4 * M.L; E.mt_rev = M.ome + 6 * M.L;

@@ -63,3 +63,23 @@ def test_work_counters_match_oracle(seed, tmp_path):
     from tools.fuzz_ref import mk
     from tools.compare_emu import run_one
     assert run_one(mk(seed), str(tmp_path), exe=util.EMU, verbose=False, trace=True)
+
+
+@pytest.mark.parametrize("tiles", ["2", "3", "5"])
+def test_emulated_lds_tiled_estep(tiles, tmp_path, monkeypatch):
+    """The >1600-column class streams the {P,Q} table through an LDS image one column tile at a time
+    (fig_hot_estep<.., TILED>).  FIG_EMU_TILES forces that form on every class, so the tile bookkeeping (placement ->
+    tile assignment, sub-windows, unit dealing, per-read arg-max slots) is compared with the reference's bytes on
+    small gaps too; the real tile sizes run in test_gpu_parity.py::test_longest_gap_class_matches_oracle."""
+    from tools.fuzz_ref import mk
+    from tools.compare_emu import run_one
+    monkeypatch.setenv("FIG_EMU_TILES", tiles)
+    for name in ("unmapped_small", "repeat_flanks", "model_indels"):
+        root = util.extract_golden(name, str(tmp_path / name))
+        r = util.run_figfill(root, util.EMU)
+        assert r.returncode == 0, r.stderr
+        assert f"LDS-tiled E-step forced, tiles={tiles} " in r.stderr          # the knob reached the emulation
+        for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+            assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), (name, fn)
+    for seed in (431, 432):
+        assert run_one(mk(seed), str(tmp_path / f"f{seed}"), exe=util.EMU, verbose=False, trace=True)
