@@ -857,6 +857,8 @@ FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
         if (cpl <= 8) fig_hot_estep<LDS, 8, true>(E, gapoffset);
         else if (cpl <= 12) fig_hot_estep<LDS, 12, true>(E, gapoffset);
         else if (cpl <= 16) fig_hot_estep<LDS, 16, true>(E, gapoffset);
+        else if (cpl <= 24) fig_hot_estep<LDS, 24, true>(E, gapoffset);          // gaps of 2049-3072 bp
+        else if (cpl <= 32) fig_hot_estep<LDS, 32, true>(E, gapoffset);          // ... -4096 bp
         else fig_hot_estep<LDS, 0, true>(E, gapoffset);
         return;
     }

@@ -224,6 +224,18 @@ def test_longest_gap_class_matches_oracle(tmp_path):
     _oracle_compare(batch, res, [0, 1, 2, 3], mc, spec, tmp_path)
 
 
+def test_gaps_wider_than_the_bench_mix_match_oracle(tmp_path):
+    """Beyond BASELINE's 2000-bp top bracket the LDS-tiled class keeps 24 / 32 register accumulators per lane in its column
+    pass (2049-3072 / 3073-4096 bp) and, past that, the generic column pass (accumulators in the scratch slab): one gap of
+    each, bytes equal the oracle's."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=160.0, gap_spacing=10000, scaffold_len=40000)
+    eng, mc = _bench_engine(spec)
+    batch, _ = synth.make_bench_batch(2031, 3, spec, gap_lengths=np.array([2600, 3500, 4500]))
+    res = eng.fill(batch)
+    eng.close()
+    _oracle_compare(batch, res, [0, 1, 2], mc, spec, tmp_path)
+
+
 def test_loguniform_mix_sample_matches_oracle(tmp_path):
     """BASELINE config 5's gap mix (length log-uniform in [50, 2000]): a seeded batch, a stratified sample of which
     (one gap per length octave, the cheapest of each for the CPU's sake) is checked against the oracle byte for byte."""
