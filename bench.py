@@ -302,6 +302,12 @@ def read_traffic(args, world):
     try:
         sc = json.load(open(TRAFFIC_SIDECAR))
         ent = sc.get(workload_key(args, world))
+        if not ent and world > 1:
+            # weak scaling: every rank fills a 512-gap shard of the same mix, so the whole-job traffic is taken as the 1-GPU
+            # pass x ranks (no PMC pass is run on the multi-GPU node)
+            e1 = sc.get(workload_key(args, 1))
+            if e1:
+                return e1["bytes_per_step"] * world, e1.get("note", "") + f" x {world} ranks, scaled from the 1-GPU PMC pass (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
         if ent:
             return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
         return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"

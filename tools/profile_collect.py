@@ -52,6 +52,13 @@ def main():
         traffic["bytes_per_step"] = 2.0 * traffic["fetch"]["bytes_per_fill_raw"] + traffic["write"]["bytes_per_fill_raw"]
         traffic["note"] = "rocprofv3 --pmc FETCH_SIZE x2 (gfx950 reports half the bytes of wide reads; upper bound for the dword scratch share) + --pmc WRITE_SIZE, fig_* kernels, per fill"
     json.dump(traffic, open(os.path.join(sm, f"{tag}_traffic.json"), "w"), indent=1)
+    if "bytes_per_step" in traffic:
+        # the sidecar bench.py reads roofline.traffic from (copy to profiles/traffic_sidecar.json): keyed like bench.workload_key()
+        # for the default command the passes above ran
+        side = {"head": os.environ.get("FIG_HEAD", tag),
+                "unmapped|gage|g512|r1000|s20260101|n1": {"bytes_per_step": traffic["bytes_per_step"], "fetch_bytes_raw": traffic["fetch"]["bytes_per_fill_raw"],
+                                                          "write_bytes": traffic["write"]["bytes_per_fill_raw"], "note": traffic["note"]}}
+        json.dump(side, open(os.path.join(sm, "traffic_sidecar.json"), "w"), indent=1)
     print(json.dumps(traffic))
 
 
