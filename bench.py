@@ -103,11 +103,20 @@ def main():
         log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfighip has no CPU path")
+    # Rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): FIGBENCH_DEVICE=<n> puts every rank on
+    # GPU n, FIGBENCH_BACKEND=gloo moves the collectives to host tensors (RCCL refuses two ranks on one device).
+    backend = os.environ.get("FIGBENCH_BACKEND", "nccl")
+    if "FIGBENCH_DEVICE" in os.environ:
+        local = int(os.environ["FIGBENCH_DEVICE"])
     torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    gdev = torch.device("cuda", local)
+    dev = gdev if backend == "nccl" else torch.device("cpu")      # where the collectives' tensors live
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=gdev)
+        else:
+            dist.init_process_group(backend)
     log(f"imports + init done (budget {args.budget_s:.0f} s)")
 
     def left():

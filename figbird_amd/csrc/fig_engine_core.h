@@ -642,6 +642,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         long long rstride = 208;
         if ((long long)nrow * rstride > (long long)E.nteams * E.Wcap) { nrow = E.nw < E.nteams ? E.nw : E.nteams; if (nrow > FIG_PLB_TEAMS) nrow = FIG_PLB_TEAMS; rstride = E.Wcap; }
         if (nrow < 1) nrow = 1;
+        FIG_TICK(E, 31);
         for (int p0 = 0; p0 < nproc; p0 += nrow) {
             const int nr = nproc - p0 < nrow ? nproc - p0 : nrow;
             if (E.wave < nr) {
@@ -685,14 +686,18 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
                 best = fig_wave_best(E, best);
                 if (E.lane == 0) { S.wv_v[E.wave] = best.v; S.wv_o[E.wave] = best.o; S.tm_lo[E.wave] = w.lo; S.tm_hi[E.wave] = w.hi; S.tm_len[E.wave] = len; }
             }
+            FIG_TICK(E, 27);
             FIG_SYNC();
+            FIG_TICK(E, 28);
             for (int t = 0; t < nr; t++) {
                 E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * rstride;
                 fig_accumulate_columns(E, S.tm_len[t], S.tm_lo[t], S.tm_hi[t], G);
                 if (E.tid == 0 && S.wv_o[t] != FIG_NOPOS) maxLikelihood += S.wv_v[t];
                 if (E.tid == 0 && E.B->dbg_read_maxlv) E.scr.maxlv[p0 + t] = S.wv_o[t] != FIG_NOPOS ? S.wv_v[t] : 0.0;   // parity plane (ii); unused otherwise
             }
+            FIG_TICK(E, 29);
             FIG_SYNC();
+            FIG_TICK(E, 30);
         }
         E.rb = rb_keep; E.wbuf = wbuf_keep;
         FIG_TICK(E, 4);
@@ -708,6 +713,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         FIG_SYNC();
         // match/mismatch table over the extended columns (overlays the {P,Q} table, which the next computeProbsGap rebuilds)
         fig_build_mle_table(E, G, left, right);          // ends with a barrier
+        FIG_TICK(E, 32);
         const double *Ctab = (const double *)E.pq;
         // one read per wave, no workgroup barrier inside the loop (the per-read results are independent)
         for (int p = E.wave; p < nproc; p += E.nw) {
@@ -761,6 +767,7 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             }
         }
         E.rb = rb_keep;
+        FIG_TICK(E, 33);
         E.flops += pfl; E.mle_alg += pml;
         { unsigned long long t = pml; for (int off = 32; off > 0; off >>= 1) t += fig_shfl_down_u64(t, off); E.mle_exec += t; }   // unpruned: executed == credited
         FIG_SYNC();
