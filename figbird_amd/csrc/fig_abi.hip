@@ -539,6 +539,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
     const int slots_cap = ctx->nslots;
     const int capacity = std::max(1, c.capacity);      // workgroups the device holds for this class (not capped by the gap count)
     const bool log = getenv("FIG_SCHED_LOG") != nullptr;
+    const double ipw = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0;
     while (true) {
@@ -550,11 +551,11 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
         round++;
         if (n_active == 0) break;
         // Candidates per gap this round: proportional to the candidates the gap still has, so that all gaps of the class
-        // finish in about the same round and every round carries ~8 items per resident workgroup.  A gap that stops
+        // finish in about the same round and every round carries ~12 items per resident workgroup (of both lanes of a split class).  A gap that stops
         // early discards at most chunk-1 evaluations.
         long long rem_total = 0;
         for (int g : ids) if (ctl[(size_t)g * 4] == 1) rem_total += std::max(0, ctl[(size_t)g * 4 + 2] - ctl[(size_t)g * 4 + 1]);
-        const double share = rem_total > 0 ? (8.0 * capacity) / (double)rem_total : 1.0;
+        const double share = rem_total > 0 ? (ipw * capacity / (double)std::max(1, c.c.nsplit)) / (double)rem_total : 1.0;
         int chunk = 0;
         items.clear(); entries.clear();
         for (int g : ids) {

@@ -86,26 +86,34 @@ FIG_D double fig_mle_chain(FigEng &E, int o, int len, int j0, int j1, int rev, i
     return q;
 }
 
-// Add the weights of the current read to the gap columns in placement order (the
-// `countsGap[i-startPos+j][...] += antilog_value` loops, Figbird.cpp:3181-3187 / :3603-3611).
-// Lanes = gap columns; at inner step s every lane looks at the same read base, so the
-// 5-way accumulator choice is wave-uniform.
-FIG_D void fig_accumulate_columns(FigEng &E, int len, int lo, int hi, int G) {
-    int cg = E.capG;
-    int xlo = lo < 0 ? 0 : lo;                    // first column any placement can reach
-    int xhi = hi + len - 1; if (xhi > G - 1) xhi = G - 1;
-    for (int x = E.tid; x <= xhi; x += E.nt) {      // column -> thread mapping independent of the read: no barrier needed between reads
-        if (x < xlo) continue;
-        int o0 = x - (len - 1); if (o0 < lo) o0 = lo;
-        int o1 = x; if (o1 > hi) o1 = hi;
-        if (o0 > o1) continue;
-        double a0 = E.scr.cnt[x], a1 = E.scr.cnt[cg + x], a2 = E.scr.cnt[2 * cg + x], a3 = E.scr.cnt[3 * cg + x], a4 = E.scr.cnt[4 * cg + x];
-        for (int o = o0; o <= o1; o++) {
-            double w = E.wbuf[o - lo];
-            int b = E.rb[x - o];
-            if (b == 0) a0 += w; else if (b == 1) a1 += w; else if (b == 2) a2 += w; else if (b == 3) a3 += w; else a4 += w;
+// Add the weights of a chunk of partial reads to the gap columns in (read, placement) order (the
+// `countsGap[i-startPos+j][...] += antilog_value` loops, Figbird.cpp:3181-3187).  Lanes = gap columns; rows t = 0..nr-1 of
+// `wrows` hold the reads' weights by placement, `codes + t*256` their base codes, S.tm_* their windows.  A column's five
+// sums are fetched from the slab once per chunk, every read adds into them in read order, and the 5-way choice is five
+// select-adds (x + 0.0 == x exactly: the sums never go negative), so lanes with different bases do not serialise and the
+// loads of consecutive placements overlap.
+FIG_D void fig_accumulate_chunk(FigEng &E, int nr, const double *wrows, long long rstride, const unsigned char *codes, int G) {
+    const FigState &S = *E.S;
+    const int cg = E.capG;
+    for (int x = E.tid; x < G; x += E.nt) {
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+        bool have = false;
+        for (int t = 0; t < nr; t++) {
+            const int lo = S.tm_lo[t], hi = S.tm_hi[t], len = S.tm_len[t];
+            int o0 = x - (len - 1); if (o0 < lo) o0 = lo;
+            int o1 = x; if (o1 > hi) o1 = hi;
+            if (o0 > o1) continue;
+            if (!have) { a0 = E.scr.cnt[x]; a1 = E.scr.cnt[cg + x]; a2 = E.scr.cnt[2 * cg + x]; a3 = E.scr.cnt[3 * cg + x]; a4 = E.scr.cnt[4 * cg + x]; have = true; }
+            const double *wr = wrows + (long long)t * rstride - lo;
+            const unsigned char *rb = codes + t * 256 + x;
+#pragma unroll 4
+            for (int o = o0; o <= o1; o++) {
+                const double w = wr[o];
+                const int b = rb[-o];
+                a0 += b == 0 ? w : 0.0; a1 += b == 1 ? w : 0.0; a2 += b == 2 ? w : 0.0; a3 += b == 3 ? w : 0.0; a4 += b > 3 ? w : 0.0;
+            }
         }
-        E.scr.cnt[x] = a0; E.scr.cnt[cg + x] = a1; E.scr.cnt[2 * cg + x] = a2; E.scr.cnt[3 * cg + x] = a3; E.scr.cnt[4 * cg + x] = a4;
+        if (have) { E.scr.cnt[x] = a0; E.scr.cnt[cg + x] = a1; E.scr.cnt[2 * cg + x] = a2; E.scr.cnt[3 * cg + x] = a3; E.scr.cnt[4 * cg + x] = a4; }
     }
 }
 
@@ -689,9 +697,8 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
             FIG_TICK(E, 27);
             FIG_SYNC();
             FIG_TICK(E, 28);
+            fig_accumulate_chunk(E, nr, wbuf_keep, rstride, (const unsigned char *)E.plb, G);
             for (int t = 0; t < nr; t++) {
-                E.rb = (unsigned char *)E.plb + t * 256; E.wbuf = wbuf_keep + (long long)t * rstride;
-                fig_accumulate_columns(E, S.tm_len[t], S.tm_lo[t], S.tm_hi[t], G);
                 if (E.tid == 0 && S.wv_o[t] != FIG_NOPOS) maxLikelihood += S.wv_v[t];
                 if (E.tid == 0 && E.B->dbg_read_maxlv) E.scr.maxlv[p0 + t] = S.wv_o[t] != FIG_NOPOS ? S.wv_v[t] : 0.0;   // parity plane (ii); unused otherwise
             }

@@ -5,6 +5,7 @@
 #ifndef FIG_PACK_H
 #define FIG_PACK_H
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "../../include/figbird_hip.h"
@@ -85,8 +86,10 @@ static inline double fig_model_fmm(const fig_model *m) {
     return f < 1.0 ? f : 1.0;
 }
 
+#define FIG_SPLIT_MIN_GAPS 96        // a class with at least this many gaps is scheduled as two lanes
 struct FigLaunchClass { int capG, capGl, ncolE, Wcap, nteams, nt; bool lds_tab; size_t lds; int q_begin, q_end;
-                        int tiles, tile_step, tile_cols, tiled_max; };     // tiled_max: doubles of LDS the table/weight area may grow to      // tiles > 0: table in HBM/L2, streamed through an LDS tile per chunk (fig_hot_estep)
+                        int tiles, tile_step, tile_cols, tiled_max;
+                        int nsplit; };     // tiled_max: doubles of LDS the table/weight area may grow to      // tiles > 0: table in HBM/L2, streamed through an LDS tile per chunk (fig_hot_estep)
 
 struct FigPacked {
     std::vector<FigDevGap> gaps;
@@ -285,10 +288,18 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
                 if (mle <= c.tiled_max && fixed + sizeof(double) * (size_t)mle > c.lds) c.lds = fixed + sizeof(double) * (size_t)mle;
             }
         }
-        c.q_begin = (int)K.order.size();
-        for (int32_t id : ids) { K.gaps[id].cls = (int)K.classes.size(); K.order.push_back(id); }
-        c.q_end = (int)K.order.size();
-        K.classes.push_back(c);
+        // A class with many gaps runs as TWO lanes of the same memory form (gaps dealt alternately in cost order), each with
+        // its own stream, queue and round sequence: one lane's persistent workgroups take over the CUs the other lane's
+        // round leaves idle while its last items finish (fig_abi.hip: run_class_parallel; nsplit halves the items per round).
+        { const char *ev = getenv("FIG_CLASS_LANES");                                   // tuning knob: lanes per large class (default 2)
+          const int want = ev ? std::max(1, std::min(8, atoi(ev))) : 2;
+          c.nsplit = (int)ids.size() >= (FIG_SPLIT_MIN_GAPS / 2) * want ? want : 1; }
+        for (int part = 0; part < c.nsplit; part++) {
+            c.q_begin = (int)K.order.size();
+            for (size_t k = (size_t)part; k < ids.size(); k += (size_t)c.nsplit) { const int32_t id = ids[k]; K.gaps[id].cls = (int)K.classes.size(); K.order.push_back(id); }
+            c.q_end = (int)K.order.size();
+            K.classes.push_back(c);
+        }
         K.capE = std::max(K.capE, c.ncolE);
         K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
     }

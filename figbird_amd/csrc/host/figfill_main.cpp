@@ -107,6 +107,7 @@ int main(int argc, char **argv) {
                 for (int k = 0; k < dn[g] && k < maxc; k++)
                     fprintf(f, "CAND\t%d\t%d\t%d\t%a\t%d\n", (int)g, di[(g * maxc + k) * 3], di[(g * maxc + k) * 3 + 1], dl[g * maxc + k], di[(g * maxc + k) * 3 + 2]);
             fprintf(f, "STATS\t%lld\t%.17g\n", (long long)st.place_calls, st.alg_flops);
+            fprintf(f, "LAUNCHES\t%d\n", (int)st.n_launches);      // kernel launches of the fill (the emulation reports its launch classes)
             fclose(f);
         }
     }

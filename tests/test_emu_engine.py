@@ -83,3 +83,30 @@ def test_emulated_lds_tiled_estep(tiles, tmp_path, monkeypatch):
             assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), (name, fn)
     for seed in (431, 432):
         assert run_one(mk(seed), str(tmp_path / f"f{seed}"), exe=util.EMU, verbose=False, trace=True)
+
+
+def test_emulated_split_class_lanes(tmp_path):
+    """A class with >= FIG_SPLIT_MIN_GAPS (96) gaps is scheduled as two lanes of the same memory form (fig_pack.h): 120
+    small gaps through the shipped host code + packer + the emulated engine give the oracle's bytes, and the packer did
+    split (FIGFILL_TRACE lists the launch classes)."""
+    import numpy as np
+    from figbird_amd import synth
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=5.0)
+    mc = synth.bench_model_case(7, spec)
+    rng = np.random.default_rng(97)
+    batch, _ = synth.make_bench_batch(97, 120, spec, gap_lengths=rng.integers(5, 26, size=120))
+    outs = {}
+    for who, exe in (("oracle", None), ("emu", util.EMU)):
+        paths = synth.write_batch_subset(batch, list(range(120)), mc, str(tmp_path / who), spec)
+        args = [paths["scf"], str(spec.max_distance), str(spec.read_len), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
+                "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
+        env = dict(os.environ)
+        if exe:
+            env["FIGFILL_TRACE"] = str(tmp_path / "emu.trace")
+        r = util.run(([util.ORACLE, "fillgaps"] if exe is None else [exe]) + args, str(tmp_path), timeout=900, env=env)
+        assert r.returncode == 0, r.stderr
+        outs[who] = {fn: util.read(paths["tmp"] + fn) for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt")}
+    assert outs["emu"] == outs["oracle"]
+    tr = util.read(str(tmp_path / "emu.trace"))
+    lanes = [int(ln.split("\t")[1]) for ln in tr.splitlines() if ln.startswith("LAUNCHES\t")]
+    assert lanes and lanes[0] >= 2, "expected the one class to be split into two lanes"
