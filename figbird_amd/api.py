@@ -42,6 +42,7 @@ class FigGapBatch(C.Structure):
         ("u_seq", C.c_char_p),
         ("p_read_off", c_i64_p), ("p_clipped_index", c_i32_p), ("p_match", c_i32_p), ("p_pos", c_i32_p),
         ("p_ref_pos", c_i32_p), ("p_seq_off", c_i64_p), ("p_seq", C.c_char_p), ("p_qual", C.c_char_p),
+        ("gap_ot_preset", c_u8_p),
     ]
 
 
@@ -213,6 +214,7 @@ class GapBatch:
     p_seq_off: np.ndarray
     p_seq: np.ndarray
     p_qual: np.ndarray
+    gap_ot_preset: Optional[np.ndarray] = None      # uint8 [n_gaps]; None = one reference process in batch order (figbird_hip.h)
 
     @property
     def n_gaps(self) -> int:
@@ -242,6 +244,7 @@ class GapBatch:
         b.p_seq_off = _p(self.p_seq_off, c_i64_p)
         b.p_seq = C.cast(self.p_seq.ctypes.data, C.c_char_p)
         b.p_qual = C.cast(self.p_qual.ctypes.data, C.c_char_p)
+        b.gap_ot_preset = _p(self.gap_ot_preset, c_u8_p) if self.gap_ot_preset is not None else None
         return b
 
 

@@ -10,32 +10,8 @@
 #include <vector>
 #include "../../include/figbird_hip.h"
 #include "fig_types.h"
+#include "fig_gaprules.h"
 // (fig_engine.h must already be included: fig_persist_layout / FigState sizes come from it)
-
-// findFrac + alloc_arg, Figbird.cpp:6879-6906, :7393-7400 (float arithmetic as in the reference)
-static void gap_alloc(const fig_model *m, int G0, int *alloc_arg, float *f1, float *f2, int *lgf) {
-    int factor = 3 * m->partial_len;
-    int mid_limitp = 2 * m->partial_len, mid_limitu = m->unm_limit;
-    float info[3] = {0, 0, 0};
-    int ret;
-    if (m->partial_flag) {
-        if (G0 <= mid_limitp / 2) { info[0] = .00001; info[1] = (float)factor / G0; ret = -1; }
-        else if (G0 <= mid_limitp) { info[0] = .00001; info[1] = 5.0; ret = 5; }
-        else { info[0] = 1; info[1] = 1; ret = 3; }
-    } else {
-        if (G0 <= mid_limitu / 3) { info[0] = .3; info[1] = (float)factor / G0; ret = -1; }
-        else if (G0 <= mid_limitu) { info[0] = .5; info[1] = 2.5; ret = 3; }
-        else { info[0] = 1; info[1] = 1; info[2] = 1; ret = 1; }
-    }
-    *alloc_arg = (ret == -1) ? factor * 3 : G0 * ret;
-    *f1 = info[0]; *f2 = info[1]; *lgf = (int)info[2];
-}
-
-static int gap_range(int G0, float f1, float f2) {
-    int gapMin = (int)(G0 * f1), gapMax = (int)(G0 * f2);
-    int r = gapMax - gapMin + 1;
-    return r < 1 ? 1 : r;
-}
 
 static inline int code_of(char c) {
     switch (c) { case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': return 3; default: return 4; }
@@ -200,23 +176,15 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
     }
     K.str_total = str_total; K.str_off[ng] = str_total;
     K.capG = (K.capG + 7) & ~7;
-    {   // which gaps find the reference's global overlap_threshold already at 5 (set by an earlier gap's candidate loop,
-        // Figbird.cpp:6317): a loop gets there unless its first initialize() leaves side_limit < 10 (:6303; computable here from
-        // the gap's distance to the contig ends, initialize_start_end :2269-2296) or closes the gap by a negative overlap (:6306;
-        // only the device knows -- such a predecessor is taken as having got there, the one approximation in this rule)
+    {   // which gaps find the reference's process-level overlap_threshold already at 5 (fig_gaprules.h): given by the caller
+        // (gap_ot_preset: it knows which worker process of the reference a gap would run in, and which gaps of that process
+        // are in other shards), else derived here for ONE process taking the gaps in batch order (numthreads = 1)
         bool reached = false;
         for (int64_t g = 0; g < ng; g++) {
             FigDevGap &d = K.gaps[g];
+            if (b->gap_ot_preset) { d.pad = b->gap_ot_preset[g] ? 1 : 0; continue; }
             d.pad = reached ? 1 : 0;
-            int sl = 30;
-            const bool skip = d.fillflag == -1;
-            const int gmin = skip ? d.G0 : (int)(d.G0 * d.gpf1);
-            const int Gs[2] = {d.G0, gmin};
-            for (int G : Gs) {
-                if (d.gapStart - m->max_distance < 0) sl = std::min<int64_t>(sl, d.gapStart);
-                if (d.gapStart + G + m->max_distance > d.contigLen) sl = (int)std::min<int64_t>(sl, d.contigLen - (d.gapStart + G));
-            }
-            if (sl >= 10) reached = true;
+            if (fig_gap_sets_overlap_threshold(m, d.gapStart, d.contigLen, d.G0, d.fillflag)) reached = true;
         }
     }
     // ---- launch classes by the longest candidate a gap can reach (LDS columns); within a class the most

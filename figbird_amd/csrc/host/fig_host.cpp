@@ -1,6 +1,7 @@
 // fig_host.cpp -- see fig_host.h.  Reference citations are to /root/reference (Figbird.cpp,
 // FillGaps.cpp, Preprocess.cpp); behaviour (including quirks) is kept.
 #include "fig_host.h"
+#include "../fig_gaprules.h"
 
 #include <algorithm>
 #include <atomic>
@@ -643,6 +644,64 @@ static bool load_batch_src(const RunArgs &a, const Scaffold &sc, const GapLines 
         B.p_read_off.push_back((int64_t)B.p_clipped_index.size());
         B.gap_fillflag.push_back(fillflag);
     }
+    assign_processes(a, sc, B);
+    return true;
+}
+
+// ------------------------------------------------------------------ the reference's worker processes
+std::vector<std::vector<int32_t>> thread_allocation(const std::vector<int32_t> &gap_len, int num_threads, int gapthresh) {
+    const int tot = (int)gap_len.size();
+    std::vector<std::vector<int32_t>> T;
+    if (tot == 0) return T;
+    if (num_threads < 1) num_threads = 1;
+    if (tot <= num_threads) {                                     // :459-463, :493-500: one gap per process
+        T.resize((size_t)tot);
+        for (int i = 0; i < tot; i++) T[(size_t)i].push_back(i);
+        return T;
+    }
+    int per;                                                      // :466-471 (float, then rounded up)
+    { const float tf = (float)(tot * 1.0 / num_threads); per = (int)tf; if (tf - (float)per > 0) per++; }
+    T.resize((size_t)num_threads);
+    std::vector<int32_t> small, large;                            // :505-531
+    for (int g = 0; g < tot; g++) (gap_len[(size_t)g] > gapthresh ? large : small).push_back(g);
+    // short gaps: round-robin over the processes (:538-579)
+    for (size_t k = 0; k < small.size(); k++) T[k % (size_t)num_threads].push_back(small[k]);
+    // long gaps: processes in descending order of remaining capacity (std::sort on {process, remaining}, as :586-603)
+    std::vector<std::vector<int>> rem((size_t)num_threads, std::vector<int>(2, 0));
+    for (int i = 0; i < num_threads; i++) { rem[(size_t)i][0] = i; rem[(size_t)i][1] = per - (int)T[(size_t)i].size(); }
+    std::sort(rem.begin(), rem.end(), [](const std::vector<int> &x, const std::vector<int> &y) { return x[1] > y[1]; });
+    size_t done = 0;
+    if ((int)large.size() <= num_threads) {                       // :611-626: one each, in that order
+        for (int i = 0; i < num_threads && done < large.size(); i++) T[(size_t)rem[(size_t)i][0]].push_back(large[done++]);
+    } else {                                                      // :628-647: fill each process up to its capacity
+        for (int i = 0; i < num_threads && done < large.size(); i++)
+            for (int j = 0; j < rem[(size_t)i][1] && done < large.size(); j++) T[(size_t)rem[(size_t)i][0]].push_back(large[done++]);
+    }
+    for (auto &t : T) std::sort(t.begin(), t.end());              // writeGapLoad :322-323
+    return T;
+}
+
+void assign_processes(const RunArgs &a, const Scaffold &sc, Batch &B) {
+    const size_t ng = B.gap_contig.size();
+    B.processes = thread_allocation(B.gap_len, a.num_threads, a.unm_limit);
+    B.gap_ot_preset.assign(ng, 0);
+    fig_model m; memset(&m, 0, sizeof(m));                        // the rule reads run parameters only
+    m.partial_flag = a.partial_flag; m.unmapped_flag = a.unmapped; m.partial_len = a.partial_len; m.unm_limit = a.unm_limit; m.max_distance = a.D;
+    for (const auto &p : B.processes) {
+        bool reached = false;
+        for (int32_t g : p) {
+            B.gap_ot_preset[(size_t)g] = reached ? 1 : 0;
+            const int c = B.gap_contig[(size_t)g];
+            if (fig_gap_sets_overlap_threshold(&m, B.gap_start[(size_t)g], sc.off[(size_t)c + 1] - sc.off[(size_t)c], B.gap_len[(size_t)g], B.gap_fillflag[(size_t)g])) reached = true;
+        }
+    }
+}
+
+bool write_gaploads(const RunArgs &a, const Batch &b, std::string &err) {
+    FILE *f = fopen((a.tmp + "gaploads.txt").c_str(), "w");
+    if (!f) { err = "can't write gaploads.txt"; return false; }
+    for (const auto &p : b.processes) { for (int32_t g : p) fprintf(f, "%d\t", g); fprintf(f, "\n"); }
+    fclose(f);
     return true;
 }
 
@@ -656,6 +715,7 @@ void Batch::view(fig_gap_batch &b, const Scaffold &sc) const {
     b.u_seq_off = u_seq_off.data(); b.u_seq = u_seq.data();
     b.p_read_off = p_read_off.data(); b.p_clipped_index = p_clipped_index.data(); b.p_match = p_match.data();
     b.p_pos = p_pos.data(); b.p_ref_pos = p_ref_pos.data(); b.p_seq_off = p_seq_off.data(); b.p_seq = p_seq.data(); b.p_qual = p_qual.data();
+    b.gap_ot_preset = gap_ot_preset.size() == gap_contig.size() && !gap_ot_preset.empty() ? gap_ot_preset.data() : nullptr;
 }
 
 // ------------------------------------------------------------------ outputs
@@ -690,7 +750,11 @@ bool write_draw(const RunArgs &a, const Batch &b, const Results &r, std::string 
         fwrite(s, 1, (size_t)slen, f);
         fprintf(f, "[%d %d isz = %d %c]\n", readno, length, isz, type);
     };
-    for (size_t g = 0; g < b.gap_contig.size(); g++) {
+    // the reference concatenates the worker processes' draw files in process order (mergeFiles, FillGaps.cpp:222-260)
+    std::vector<size_t> order;
+    for (const auto &p : b.processes) for (int32_t g : p) order.push_back((size_t)g);
+    if (order.size() != b.gap_contig.size()) { order.clear(); for (size_t g = 0; g < b.gap_contig.size(); g++) order.push_back(g); }
+    for (size_t g : order) {
         int lu = r.draw_len[g * 2], lp = r.draw_len[g * 2 + 1];
         if (lu >= 0) {
             header((int)g, lu);
@@ -844,6 +908,7 @@ extern "C" int fighost_run_shard(void *h, const int64_t *ids, int64_t n, fig_gap
         S.gap_contig.push_back(B.gap_contig[g]); S.gap_start.push_back(B.gap_start[g]); S.gap_len.push_back(B.gap_len[g]);
         for (int q = 0; q < 3; q++) S.gap_stat2.push_back(B.gap_stat2[g * 3 + q]);
         S.gap_fillflag.push_back(B.gap_fillflag[g]);
+        S.gap_ot_preset.push_back(B.gap_ot_preset.size() == (size_t)ng ? B.gap_ot_preset[g] : 0);
         for (int64_t i = B.u_read_off[g]; i < B.u_read_off[g + 1]; i++) {
             S.u_anchor_pos.push_back(B.u_anchor_pos[i]); S.u_is_reverse.push_back(B.u_is_reverse[i]);
             S.u_seq.append(B.u_seq, (size_t)B.u_seq_off[i], (size_t)(B.u_seq_off[i + 1] - B.u_seq_off[i]));
@@ -878,7 +943,8 @@ extern "C" int fighost_run_write(void *h, const int32_t *filled_len, const int32
         R.draw_pos.assign(draw_pos, draw_pos + nr); R.draw_isz.assign(draw_isz, draw_isz + nr); R.draw_len.assign(draw_len, draw_len + 2 * ng);
     }
     std::string e;
-    if (!fighost::write_gapout(r->a, r->B, R, e) || !fighost::write_draw(r->a, r->B, R, e) || !fighost::write_scaffold(r->a, r->sc, r->B, R, e)) {
+    if (!fighost::write_gapout(r->a, r->B, R, e) || !fighost::write_draw(r->a, r->B, R, e) || !fighost::write_gaploads(r->a, r->B, e) ||
+        !fighost::write_scaffold(r->a, r->sc, r->B, R, e)) {
         set_err(err, errcap, e); return -1;
     }
     return 0;

@@ -47,8 +47,21 @@ struct Batch {                      // owns the arrays fig_gap_batch points into
     std::vector<uint8_t> u_is_reverse;
     std::string u_seq, p_seq, p_qual;
     std::vector<std::string> messages;      // stdout lines the reference prints while parsing
+    // the reference's worker processes (assign_processes): gap ids per process in the order it fills them, and per gap
+    // whether its process has set overlap_threshold before it gets there (fig_gap_batch::gap_ot_preset)
+    std::vector<std::vector<int32_t>> processes;
+    std::vector<uint8_t> gap_ot_preset;
     void view(fig_gap_batch &b, const Scaffold &sc) const;
 };
+
+// FillGaps.cpp:456-649 + writeGapLoad :313-334: the gaps each of the $num_threads worker processes fills, ascending within
+// a process.  (Gaps of at most `gapthresh` = 400 bp are dealt round-robin, the longer ones fill the processes up in the
+// order of their remaining capacity.)
+std::vector<std::vector<int32_t>> thread_allocation(const std::vector<int32_t> &gap_len, int num_threads, int gapthresh = 400);
+// Fills B.processes / B.gap_ot_preset for the run `a` (needs only the run parameters, not the model tables).
+void assign_processes(const RunArgs &a, const Scaffold &sc, Batch &B);
+// gaploads.txt as the reference leaves it in Temp/ (one line of tab-terminated gap ids per process)
+bool write_gaploads(const RunArgs &a, const Batch &b, std::string &err);
 
 // gapInfo.txt, stat2.txt, gaps_<g>.sam (parseUnmapped, Figbird.cpp:5661-5767), partial_gaps_<g>.sam
 bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &out, std::string &err);

@@ -98,6 +98,7 @@ int main(int argc, char **argv) {
 
     if (!write_gapout(a, B, R, err)) return fail(err);
     if (!write_draw(a, B, R, err)) return fail(err);
+    if (!write_gaploads(a, B, err)) return fail(err);
     if (!write_scaffold(a, sc, B, R, err)) return fail(err);
     if (trace) {
         FILE *f = fopen(trace, "w");

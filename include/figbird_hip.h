@@ -92,6 +92,12 @@ typedef struct fig_gap_batch {
     const int64_t *p_seq_off;           /* [n_preads+1] offsets into p_seq and p_qual       */
     const char *p_seq;
     const char *p_qual;                 /* phred+33, same offsets as p_seq (may be NULL in unmapped mode) */
+    /* state the reference carries from gap to gap inside ONE worker process (FillGaps.cpp:456-649 deals the gaps to
+     * $num_threads processes, each running Figbird.cpp main over its list in ascending gap order): [n_gaps] 1 when that
+     * process has already set its global overlap_threshold (Figbird.cpp:103, :6317) by the time it gets to the gap.
+     * NULL = the batch is one process taking the gaps in batch order (numthreads = 1).  A caller that fills a SHARD
+     * of a run must pass it, because the gap that set the value may be in another shard (fig_host.cpp: assign_processes). */
+    const uint8_t *gap_ot_preset;
 } fig_gap_batch;
 
 /* Results = what Figbird.cpp writes per gap: the gapout line (:7411-7413) and

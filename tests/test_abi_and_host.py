@@ -131,3 +131,28 @@ def test_model_build_threads_agree(tmp_path, monkeypatch):
         for x, y in ((a.e, b.e), (a.ins, b.ins), (a.dele, b.dele), (a.T, b.T), (a.insd, b.insd)):
             assert np.array_equal(x, y)
     assert a.ins.max() > a.ins.min()            # the indel reads really fed inPosDist
+
+
+@pytest.mark.skipif(not os.path.exists(os.path.join(os.path.dirname(util.REF_FIGBIRD), "FillGaps.out")) or not os.path.exists("/root/reference/Figbird.cpp"),
+                    reason="needs oracle/_ref (the reference compiled in place) and the reference checkout")
+@pytest.mark.parametrize("lens,threads", [([20, 500, 25, 600, 18, 33, 700], 5), ([500, 20, 600, 700, 30, 800, 900, 450, 25, 1000, 40, 1100], 3)])
+def test_gap_deal_matches_live_reference(lens, threads, tmp_path):
+    """FillGaps.cpp:456-649 deals the gaps to $num_threads worker processes (short gaps in turn, long ones by remaining
+    capacity); `figfill` reproduces it (fig_host.cpp: thread_allocation) for gaploads.txt, the order of draw.txt and the
+    process-level overlap_threshold, and so does the oracle.  Read-less gaps keep this quick: the reference compiles
+    Figbird.cpp once per process.  (The committed `threads3` fixture pins the short-gap branch with reads.)"""
+    from figbird_amd import synth
+    specs, pos = [], 300
+    for n in lens:
+        specs.append((pos, n)); pos += n + 400
+    case = synth.make_case("deal", 5, "unmapped", specs, contig_len=pos + 400, coverage=0.0, n_model_pairs=300)
+    outs = {}
+    for tag, exe in (("ref", [os.path.join(os.path.dirname(util.REF_FIGBIRD), "FillGaps.out")]), ("host", [util.EMU]), ("oracle", [util.ORACLE, "fillgaps"])):
+        p = synth.write_case(case, str(tmp_path / tag))
+        cwd = tmp_path / ("cwd_" + tag); cwd.mkdir()
+        os.symlink("/root/reference/Figbird.cpp", str(cwd / "Figbird.cpp"))         # FillGaps.out shells out to g++ Figbird.cpp
+        r = util.run(exe + synth.fillgaps_argv(case, p, n_threads=threads), str(cwd), timeout=600)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = {fn: util.read(p["tmp"] + fn) for fn in ("gaploads.txt", "draw.txt", "gapout.txt", "filledContigs.fa")}
+    assert outs["host"] == outs["ref"]
+    assert outs["oracle"] == outs["ref"]

@@ -14,7 +14,7 @@ def test_emulated_engine_matches_reference_outputs(name, tmp_path):
     root = util.extract_golden(name, str(tmp_path))
     r = util.run_figfill(root, util.EMU)
     assert r.returncode == 0, r.stderr
-    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+    for fn in util.ref_files(root):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
 
 

@@ -78,7 +78,7 @@ def _mp_worker(rank, world, port, root, name, q):
     q.put((rank, rc))
 
 
-@pytest.mark.parametrize("name,world", [("unmapped_mid_err", 2), ("partial_brackets", 2), ("edge_contig_ends", 3)])
+@pytest.mark.parametrize("name,world", [("unmapped_mid_err", 2), ("partial_brackets", 2), ("edge_contig_ends", 3), ("threads3", 2)])
 def test_figfill_mp_writes_the_reference_files(name, world, tmp_path):
     """The multi-GPU product path (figbird_amd.figfill_mp: run handle -> LPT shards -> C ABI -> one packed all-gather ->
     rank 0 writes) on `world` gloo ranks: gapout.txt, draw.txt, filledContigs.fa and Ncount.txt byte-identical to the
@@ -96,7 +96,7 @@ def test_figfill_mp_writes_the_reference_files(name, world, tmp_path):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(rc == 0 for _, rc in outs)
-    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+    for fn in util.ref_files(root):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
 
 

@@ -23,7 +23,7 @@ def test_oracle_matches_reference_fillgaps_main(name, tmp_path):
     root = util.extract_golden(name, str(tmp_path))
     r = util.run_oracle_fillgaps(root)
     assert r.returncode == 0, r.stderr
-    for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+    for fn in util.ref_files(root):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
 
 

@@ -77,3 +77,12 @@ def parse_trace(path: str):
         elif f[0] == "MODEL":
             model = (int(f[1]), int(f[2]), int(f[3]), float.fromhex(f[4]), float.fromhex(f[5]), float.fromhex(f[6]))
     return cands, model
+
+
+def ref_files(root: str):
+    """The files of a fill golden to byte-compare: the four RunFigbird.sh moves, plus gaploads.txt when the fixture was made
+    with $num_threads > 1 (the reference's gap -> worker-process deal, FillGaps.cpp:313-334)."""
+    fns = ["gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"]
+    if os.path.exists(os.path.join(root, "ref", "gaploads.txt")):
+        fns.append("gaploads.txt")
+    return fns

@@ -34,7 +34,12 @@ CASES = {
     "stat2_hint": dict(seed=81, mode="partial", gap_specs=[(2000, 14), (4000, 18), (6000, 30)], insert_mean=180, insert_sd=10, coverage=24, err=0.003,
                        n_model_pairs=800, contig_len=8000),
     "model_indels": dict(seed=91, mode="unmapped", gap_specs=[(3000, 28), (6000, 150)], coverage=10, err=0.01, n_model_pairs=900, model_indel_rate=0.12),
+    # $num_threads = 3: FillGaps.cpp:456-649 deals the gaps to three worker processes (gaploads.txt), draw.txt is their
+    # draw files one after the other, and each process starts with its own overlap_threshold = 0 (Figbird.cpp:103, :6317)
+    "threads3": dict(seed=977, mode="partial", gap_specs=[(1000, 30), (2000, 35), (3000, 24), (4000, 35), (5000, 28), (6000, 40), (7000, 33), (7900, 450)],
+                     contig_len=9500, insert_mean=180, insert_sd=10, coverage=18, err=0.003, n_model_pairs=600),
 }
+N_THREADS = {"threads3": 3}
 
 
 def _post_edge_no_reads(case):
@@ -80,7 +85,24 @@ def _post_stat2_hint(case):
     case.gaps[2].stat2 = (1, 1, 25)           # G0 = 30 > 20: the hint must be ignored
 
 
-POST = {"edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
+def _post_threads3(case):
+    """Gaps 1-3 get only a few hand-placed partial reads whose left- and right-hanging ends overlap by 2-4 bases: the overlaps
+    detect_overlap_gapestimate (Figbird.cpp:2512-2700) judges against overlap_threshold, which is 0 for the first gap of a
+    worker process and 5 for the later ones."""
+    s = case.scaffolds[0]; L = case.read_len
+    for gi, (into_left, clip_right) in {1: ((20, 16), (18, 12)), 3: ((19, 15), (18, 14)), 2: ((14, 10), (12, 9))}.items():
+        g = case.gaps[gi]
+        reads = []
+        for k in into_left:
+            al = L - k; pos1 = g.start - al + 1
+            reads.append(synth.PartialRead(s[g.start - al:g.start] + g.truth[:k], g.start - pos1, 1, pos1, f"{al}M{k}S", -1, "I" * L))
+        for c in clip_right:
+            al = L - c
+            reads.append(synth.PartialRead(g.truth[len(g.truth) - c:] + s[g.start + g.length:g.start + g.length + al], c, 2, g.start + g.length + 1, f"{c}S{al}M", -1, "I" * L))
+        g.partial = reads
+
+
+POST = {"threads3": _post_threads3, "edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
 
 
 def make(name):
@@ -108,13 +130,17 @@ def build(name, kw=None, keep=None):
     # FillGaps.out shells out to `g++ Figbird.cpp`: give it a scratch cwd with a symlink to the reference source
     cwd = os.path.join(base, "cwd"); os.makedirs(cwd)
     os.symlink("/root/reference/Figbird.cpp", os.path.join(cwd, "Figbird.cpp"))
-    r = subprocess.run([os.path.join(REF, "FillGaps.out")] + synth.fillgaps_argv(case, p, n_threads=1), capture_output=True, text=True, cwd=cwd)
+    nthr = N_THREADS.get(name, 1)
+    r = subprocess.run([os.path.join(REF, "FillGaps.out")] + synth.fillgaps_argv(case, p, n_threads=nthr), capture_output=True, text=True, cwd=cwd)
     assert r.returncode == 0, r.stderr
     for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
         shutil.move(p["tmp"] + fn, os.path.join(refdir, fn))
-    os.remove(p["tmp"] + "gaploads.txt")
+    if nthr > 1:
+        shutil.move(p["tmp"] + "gaploads.txt", os.path.join(refdir, "gaploads.txt"))      # FillGaps.cpp:313-334, as the reference left it
+    else:
+        os.remove(p["tmp"] + "gaploads.txt")
     meta = {"name": name, "figbird_argv": ["scf.fa"] + synth.figbird_argv(case, p)[1:8] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.figbird_argv(case, p)[11:],
-            "fillgaps_argv": ["scf.fa"] + synth.fillgaps_argv(case, p)[1:7] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.fillgaps_argv(case, p)[10:],
+            "fillgaps_argv": ["scf.fa"] + synth.fillgaps_argv(case, p, n_threads=nthr)[1:7] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.fillgaps_argv(case, p)[10:],
             "mode": case.mode, "n_gaps": len(case.gaps), "truth": [g.truth for g in case.gaps]}
     with open(os.path.join(root, "meta.json"), "w") as f:
         json.dump(meta, f)
