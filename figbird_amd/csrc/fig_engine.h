@@ -29,6 +29,7 @@
 #include <cmath>
 #include <cstring>
 #define FIG_D static inline
+#define FIG_NOINLINE
 #define FIG_HD static inline
 #define FIG_SYNC() ((void)0)
 FIG_D double fig_log10(double x) { return log10(x); }
@@ -45,6 +46,9 @@ FIG_D unsigned long long fig_shfl_down_u64(unsigned long long v, int off) { (voi
 #else
 #include <hip/hip_runtime.h>
 #define FIG_D __device__ static
+// kept out of line on purpose: a dispatcher that inlines one of its big callees uses all 256 VGPRs itself and then saves and
+// restores ~100 callee-saved registers per lane on every call (fig_hot_estep_dispatch did so with the tiled variants)
+#define FIG_NOINLINE __attribute__((noinline))
 #define FIG_HD __host__ __device__ static
 #ifdef FIG_PROF
 // diagnostic build: every lane accumulates the cycles it spends in workgroup barriers (E must be in scope)

@@ -485,7 +485,7 @@ FIG_D void fig_tile_copy(FigEng &E, int x0, int tcols) {
 // ---------------------------------------------------------------------------------------
 // E-step over all unmapped reads of the gap (Figbird.cpp:3530-3689).  CPL = columns per lane.
 template <bool LDS, int CPL, bool TILED>
-FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
+FIG_NOINLINE FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     FigState &S = *E.S;
     const FigHotU U = fig_hot_uniforms(E);
     const int G = U.G, left = U.left, nU = U.nU, cg = U.cg;
