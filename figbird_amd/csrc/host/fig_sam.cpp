@@ -44,9 +44,36 @@ struct State {
     long totalCount = 0, unCount = 0; unsigned long maxReadLength = 0;
     int read_mean = 0;
     int cigar_val[3] = {0, 0, 0};
-    std::string myout;                  // text of myout.sam
+    std::string myout;                  // text of myout.sam not yet written (streamed out in ~1 MB pieces)
+    FILE *myout_file = nullptr; bool myout_failed = false;
+    bool account = false;               // first pass of a far jump library: every line written also feeds the insert-size histogram
+    std::vector<long> insertCounts; long discarded = 0;
     FILE *out1 = nullptr, *out2 = nullptr; bool writeflag = false;
 };
+
+// processMapping over a line of myout.sam as the reference re-reads it (:1768-1830): strtok on tabs (empty fields vanish),
+// insert size = 6th token, MD / IH from the tokens behind the 7th
+void account_myout_line(State &S, const char *p, size_t n) {
+    const char *f[16]; size_t fl[16]; int nf = 0;
+    size_t q = 0;
+    while (q <= n && nf < 16) { size_t t = q; while (t < n && p[t] != '\t') t++; if (t > q) { f[nf] = p + q; fl[nf] = t - q; nf++; } q = t + 1; }
+    if (nf < 7) return;
+    const int insertSize = atoi(std::string(f[5], fl[5]).c_str());
+    const char *md = nullptr; size_t mdl = 0; int nh = 0;
+    for (int k = 7; k < nf; k++) {
+        if (fl[k] >= 2 && f[k][0] == 'M' && f[k][1] == 'D') { md = f[k]; mdl = fl[k]; }
+        else if (fl[k] >= 2 && f[k][0] == 'I' && f[k][1] == 'H') nh = fl[k] > 5 ? atoi(std::string(f[k] + 5, fl[k] - 5).c_str()) : 0;
+    }
+    if (nh == 1 && !(mdl > 5 && md[5] == '^')) {
+        const long c = atol(std::string(f[2], fl[2]).c_str());
+        if (c >= 0 && c < (long)S.contigs.size() && !S.contigs[(size_t)c].empty()) {
+            if (insertSize > 0) { if (insertSize < kMaxFragment) S.insertCounts[(size_t)insertSize]++; else if (insertSize > kMaxFragment) S.discarded++; }
+        }
+    }
+}
+
+// a record for myout.sam: appended to the pending text, accounted when asked, and the text handed to the file in pieces
+void myout_line(State &S, const Sam &r);
 
 std::string revcomp(const std::string &s) {     // reverse(), :145-166
     std::string r(s.size(), 'N');
@@ -91,6 +118,16 @@ void sam_line(std::string &dst, const Sam &r) {     // writeSam / writeSam2, :40
     snprintf(buf, sizeof buf, "%d\t", r.tlen); dst += buf;
     dst += r.seq; dst += '\t'; dst += r.qual; dst += '\t'; dst += r.md;
     snprintf(buf, sizeof buf, "\tIH:i:%ld\n", r.ih); dst += buf;
+}
+
+void myout_line(State &S, const Sam &r) {
+    const size_t at = S.myout.size();
+    sam_line(S.myout, r);
+    if (S.account) account_myout_line(S, S.myout.data() + at, S.myout.size() - at - 1);
+    if (S.myout.size() >= (1u << 20)) {
+        if (S.myout_file && fwrite(S.myout.data(), 1, S.myout.size(), S.myout_file) != S.myout.size()) S.myout_failed = true;
+        S.myout.clear();
+    }
 }
 
 int parse_del(const std::string &cigar) {           // parseDel, :168-200: leading soft clip length (S before the first M)
@@ -293,7 +330,7 @@ void print_vectors(State &S, std::vector<Sam> &reads1, std::vector<Sam> &reads2)
             r1.ih = (long)ih;
             if (r2.seq.size() > S.maxReadLength) S.maxReadLength = r2.seq.size();
             r2.ih = (long)ih;
-            sam_line(S.myout, r1); sam_line(S.myout, r2);
+            myout_line(S, r1); myout_line(S, r2);
         }
     }
     S.totalCount++;
@@ -465,8 +502,14 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
     const bool jump_far = a.samflag == 2 && a.maxDistance > 250;
     std::string preq1 = "*", preq2 = "*";
     auto next_line = [&]() { return fgets(line.data(), kRec, mapFile) != nullptr; };
+    if (write_mode) {
+        S.myout_file = fopen(a.outFile.c_str(), "w");
+        if (!S.myout_file) { err = "Can't create myout file"; return 1; }
+    }
     if (jump_far) {
         // ---- first pass (:2278-2435): properly paired records -> myout.sam, then the mean insert size read_mean
+        // (the reference re-reads the file it has just written, processMapping :1768-1830; here each line is accounted as it is written)
+        S.account = true; S.insertCounts.assign((size_t)kMaxFragment, 1); S.discarded = 0;
         bool end = false;
         while (next_line()) {
             if (line[0] == '@') continue;
@@ -484,31 +527,12 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
             if (!next_line()) break;
             Sam read2; if (!get_sam(S, line.data(), read2)) break;
             if (read1.qname != preq1 || read2.qname != preq2) { preq1 = read1.qname; preq2 = read2.qname; print_vectors(S, reads1, reads2); }
-            reads1.push_back(read1); reads2.push_back(read2);
+            reads1.push_back(std::move(read1)); reads2.push_back(std::move(read2));
         }
         print_vectors(S, reads1, reads2);
-        std::vector<long> insertCounts((size_t)kMaxFragment, 1);
-        long discarded = 0;
-        {   // processMapping over the lines just written (:1768-1830)
-            size_t p = 0;
-            while (p < S.myout.size()) {
-                size_t e = S.myout.find('\n', p); if (e == std::string::npos) e = S.myout.size();
-                std::string ln = S.myout.substr(p, e - p); p = e + 1;
-                std::vector<std::string> f; { size_t q = 0; while (q <= ln.size()) { size_t t = ln.find('\t', q); if (t == std::string::npos) t = ln.size(); if (t > q) f.push_back(ln.substr(q, t - q)); q = t + 1; } }
-                if (f.size() < 7) continue;
-                const int insertSize = atoi(f[5].c_str());
-                std::string md; int nh = 0;
-                for (size_t k = 7; k < f.size(); k++) { if (f[k][0] == 'M' && f[k][1] == 'D') md = f[k]; else if (f[k][0] == 'I' && f[k][1] == 'H') nh = f[k].size() > 5 ? atoi(f[k].c_str() + 5) : 0; }
-                if (nh == 1 && !(md.size() > 5 && md[5] == '^')) {
-                    const long c = atol(f[2].c_str());
-                    if (c >= 0 && c < (long)S.contigs.size() && !S.contigs[(size_t)c].empty()) {
-                        if (insertSize > 0) { if (insertSize < kMaxFragment) insertCounts[(size_t)insertSize]++; else if (insertSize > kMaxFragment) discarded++; }
-                    }
-                }
-            }
-        }
-        long insCount = discarded; double sum = 0;
-        for (long i = 0; i < kMaxFragment; i++) { insCount += insertCounts[(size_t)i] - 1; sum += i * (insertCounts[(size_t)i] - 1); }
+        S.account = false;
+        long insCount = S.discarded; double sum = 0;
+        for (long i = 0; i < kMaxFragment; i++) { insCount += S.insertCounts[(size_t)i] - 1; sum += i * (S.insertCounts[(size_t)i] - 1); }
         S.read_mean = (int)(sum / insCount);
         fclose(mapFile);
         mapFile = fopen(a.mapFile.c_str(), "r");
@@ -560,12 +584,13 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
     if (S.out1) fclose(S.out1);
     if (S.out2) fclose(S.out2);
     // ---- results
-    out.gaps = S.gaps; out.gap_files = S.gap_text; out.partial_files = S.partial_text; out.perfect_gap = S.perfect_gap; out.perfect_len = S.perfect_len;
+    out.gaps = S.gaps; out.perfect_gap = S.perfect_gap; out.perfect_len = S.perfect_len;
     out.totalCount = S.totalCount; out.unCount = S.unCount; out.maxReadLength = S.maxReadLength;
     if (write_mode) {
         auto put = [&](const std::string &path, const std::string &text) { FILE *f = fopen(path.c_str(), "w"); if (!f) return false; fwrite(text.data(), 1, text.size(), f); fclose(f); return true; };
         if (!put(a.tmpDir + "gapInfo.txt", gapInfo)) { err = "can't write gapInfo.txt"; return 1; }
-        if (!put(a.outFile, S.myout)) { err = "Can't create myout file"; return 1; }
+        if (fwrite(S.myout.data(), 1, S.myout.size(), S.myout_file) != S.myout.size() || S.myout_failed) { fclose(S.myout_file); err = "Can't create myout file"; return 1; }
+        fclose(S.myout_file); S.myout_file = nullptr; S.myout.clear();
         char buf[128];
         snprintf(buf, sizeof buf, "%ld %ld %ld %ld", S.totalCount, S.unCount, (long)S.maxReadLength, kMaxFragment);
         if (!put(a.tmpDir + "stat.txt", buf)) { err = "can't write stat.txt"; return 1; }
@@ -577,6 +602,7 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
             if (!put(nm, a.samflag == 2 ? S.gap_text[g] : S.partial_text[g])) { err = "can't write " + nm; return 1; }
         }
     }
+    out.gap_files = std::move(S.gap_text); out.partial_files = std::move(S.partial_text);
     return 0;
 }
 
