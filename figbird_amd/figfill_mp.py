@@ -120,7 +120,10 @@ def main():
         sys.stderr.write("usage: [torchrun ...] -m figbird_amd.figfill_mp <contigs.fa> <maxDistance> <readLen> <scriptItr> <partialFlag> <unmapped> "
                          "<numThreads> <myout.sam> <tmp/> <gaps/> <negOverlap> <partialReadLen> <trim> <setInputMean> <insertSize>\n")
         sys.exit(1)
-    sys.exit(run(sys.argv[1:16]))
+    # FIGFILL_DEVICE=<n>: every rank on GPU n; FIGFILL_MP_BACKEND=gloo: host-side all-gather (rehearsal on a box with fewer GPUs
+    # than ranks -- RCCL refuses two ranks on one device)
+    dev = os.environ.get("FIGFILL_DEVICE")
+    sys.exit(run(sys.argv[1:16], backend=os.environ.get("FIGFILL_MP_BACKEND"), device_index=int(dev) if dev is not None else None))
 
 
 if __name__ == "__main__":

@@ -69,12 +69,12 @@ def test_two_rank_shard_and_gather_reproduces_the_reference(tmp_path):
         assert ss == [e[5] if len(e) > 5 else "" for e in exp]
 
 
-def _mp_worker(rank, world, port, root, name, q):
+def _mp_worker(rank, world, port, root, name, q, lib=util.EMULIB):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
     sys.path.insert(0, util.ROOT)
     from figbird_amd import figfill_mp
     os.chdir(root)
-    rc = figfill_mp.run(util.meta(root)["fillgaps_argv"], backend="gloo", lib_path=util.EMULIB, device_index=0, verbose=False)
+    rc = figfill_mp.run(util.meta(root)["fillgaps_argv"], backend="gloo", lib_path=lib, device_index=0, verbose=False)
     q.put((rank, rc))
 
 
@@ -123,4 +123,26 @@ def test_figfill_mp_on_the_device_single_rank(tmp_path, monkeypatch):
     assert figfill_mp.run(util.meta(root)["fillgaps_argv"], device_index=0, verbose=False) == 0
     assert "libfighip.so" in open("/proc/self/maps").read()
     for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+@pytest.mark.gpu
+def test_figfill_mp_two_ranks_on_the_device(tmp_path):
+    """The launcher's N = 2 path with the real library: two rank processes share the box's one MI355X (gloo for the
+    all-gather, since RCCL refuses two ranks on one device), each fills its shard through libfighip.so, rank 0 writes.  On the
+    `threads3` fixture, so the per-process overlap_threshold presets travel with the shards."""
+    import torch.multiprocessing as mp
+    root = util.extract_golden("threads3", str(tmp_path))
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_mp_worker, args=(r, 2, port, root, "threads3", q, None)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(rc == 0 for _, rc in outs)
+    for fn in util.ref_files(root):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
