@@ -16,7 +16,8 @@ def main():
     n_gaps = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     read_len = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     out = sys.argv[3] if len(sys.argv) > 3 else None
-    spec = synth.BenchSpec(mode="unmapped", read_len=read_len, insert_mean=2500.0, insert_sd=250.0, reads_per_gap_mean=1000.0,
+    insert = float(os.environ.get("FIG_CFG4_INSERT", "2500"))      # 3500 = the bench's jump library
+    spec = synth.BenchSpec(mode="unmapped", read_len=read_len, insert_mean=insert, insert_sd=insert / 10, reads_per_gap_mean=1000.0,
                            frag_len=min(101, read_len))      # partial reads longer than the run's maxReadLength are outside the envelope (FIG_EUNSUP)
     mc = synth.bench_model_case(7, spec)
     work = tempfile.mkdtemp(prefix="figcfg4_")
@@ -48,7 +49,7 @@ def main():
         a = np.frombuffer(s.encode(), dtype=np.uint8)
         m = a != ord("N")
         called += int(m.sum()); mism += int((a[m] != t[m]).sum())
-    line = {"workload": f"config-4 shape: {n_gaps} gaps (GAGE mix), 2x{read_len}-bp jump reads (insert 2500+-250), {n_reads} reads, one unmapped-mode fill on 1 MI355X",
+    line = {"workload": f"config-4 shape: {n_gaps} gaps (GAGE mix), 2x{read_len}-bp jump reads (insert {int(insert)}+-{int(insert / 10)}), {n_reads} reads, one unmapped-mode fill on 1 MI355X",
             "n_gaps": n_gaps, "n_reads": n_reads, "gen_s": round(t_gen, 2), "pack_upload_s": round(t_up, 2), "fill_wall_s": round(t_fill, 2),
             "kernel_ms": round(st["kernel_ms"], 1), "gaps_per_s": round(n_gaps / max(st["kernel_ms"] / 1e3, 1e-9), 2),
             "filled_bases": int(res.filled_bases), "filled_bases_per_s": round(res.filled_bases / max(st["kernel_ms"] / 1e3, 1e-9), 1),
