@@ -539,6 +539,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
     const int slots_cap = ctx->nslots;
     const int capacity = std::max(1, c.capacity);      // workgroups the device holds for this class (not capped by the gap count)
     const bool log = getenv("FIG_SCHED_LOG") != nullptr;
+    const int minc = getenv("FIG_MIN_CHUNK") ? std::max(1, atoi(getenv("FIG_MIN_CHUNK"))) : 16;      // candidates per gap and round, at least
     const double ipw = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0;
@@ -556,16 +557,26 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
         long long rem_total = 0;
         for (int g : ids) if (ctl[(size_t)g * 4] == 1) rem_total += std::max(0, ctl[(size_t)g * 4 + 2] - ctl[(size_t)g * 4 + 1]);
         const double share = rem_total > 0 ? (ipw * capacity / (double)std::max(1, c.c.nsplit)) / (double)rem_total : 1.0;
+        // Admission: a gap gets at least `minc` candidates in a round it takes part in, and gaps are admitted in cost order
+        // until the round is full.  With thousands of active gaps the proportional share alone would hand every gap a few
+        // candidates per round: hundreds of rounds per gap and, worse, hundreds of DIFFERENT gaps in flight at once, whose
+        // reads then miss the L2 (a 2048-gap fill ran at 0.33 of peak against 0.37 for 512 gaps).  Workgroups that pop
+        // neighbouring items work on the same gap's reads.
+        const double target = ipw * capacity / (double)std::max(1, c.c.nsplit);
+        long long total = 0;
         int chunk = 0;
         items.clear(); entries.clear();
         for (int g : ids) {
             if (ctl[(size_t)g * 4] != 1) continue;
+            if ((double)total >= 1.25 * target) break;           // the rest waits for a later round
             int j = ctl[(size_t)g * 4 + 1], range = ctl[(size_t)g * 4 + 2];
             int want = (int)std::ceil((range - j) * share);
-            want = std::max(2, std::min(want, slots_cap));
+            want = std::max(minc, std::min(want, slots_cap));
+            want = std::min(want, slots_cap);
             int n = std::min(want, range - j);
-            if (n <= 0) { n = 0; }
+            if (n <= 0) { n = 0; }                                // (replayed with nothing to evaluate: the replay closes the gap)
             chunk = std::max(chunk, n);
+            total += n;
             entries.push_back(g); entries.push_back(n); entries.push_back(0); entries.push_back(0);
         }
         // items gap-major in descending-cost gap order (longest processing time first keeps the round's tail short)
