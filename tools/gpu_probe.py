@@ -15,6 +15,9 @@ def model_for(spec, seed=7):
     return m, mc
 
 if __name__ == "__main__":
+    if os.environ.get("FIG_PROBE_TORCH"):          # A/B: does it matter that torch initialised the HIP runtime first (as in bench.py)?
+        import torch
+        torch.cuda.init(); torch.zeros(1, device="cuda")
     mode = sys.argv[1]
     lens = [int(x) if x != "mix" else -1 for x in sys.argv[2].split(",")]     # "mix": the default bench batch (GAGE gap mix, bench seed)
     reps = int(sys.argv[3])

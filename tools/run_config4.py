@@ -13,6 +13,9 @@ from figbird_amd import api, synth
 
 
 def main():
+    if os.environ.get("FIG_PROBE_TORCH"):          # A/B: torch (and the HIP runtime it brings) initialised first, as in bench.py
+        import torch
+        torch.cuda.init(); torch.zeros(1, device="cuda")
     n_gaps = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
     read_len = int(sys.argv[2]) if len(sys.argv) > 2 else 100
     out = sys.argv[3] if len(sys.argv) > 3 else None
@@ -24,11 +27,29 @@ def main():
     mp = synth.write_case(mc, os.path.join(work, "model"))
     model = api.model_from_files(mp["scf"], mp["tmp"], mp["myout"], partial_flag=0, unmapped_flag=1, script_itr=1,
                                  max_distance=spec.max_distance, read_length=spec.read_len, neg_overlap=30, partial_len=mc.partial_len)
-    t0 = time.time(); batch, truth = synth.make_bench_batch(4004, n_gaps, spec); t_gen = time.time() - t0
+    t0 = time.time(); batch, truth = synth.make_bench_batch(int(os.environ.get("FIG_CFG4_SEED", "4004")), n_gaps, spec); t_gen = time.time() - t0
     n_reads = int(batch.u_read_off[-1])
     print(f"[config4] {n_gaps} gaps, {n_reads} reads generated in {t_gen:.1f} s", flush=True)
     eng = api.Engine(0)
     eng.set_model(model)
+    sub = int(os.environ.get("FIG_CFG4_SUBBATCH", "0"))
+    if sub > 0:
+        # the same gaps as consecutive fills of `sub` gaps each (dealt round-robin in file order, so every fill sees the same mix)
+        tot_ms = tot_fl = 0.0; filled = 0; t0 = time.time()
+        for k in range(0, (n_gaps + sub - 1) // sub):
+            ids = list(range(k, n_gaps, (n_gaps + sub - 1) // sub))
+            sb = synth.subset_batch(batch, ids)
+            r = eng.fill(sb); st = eng.stats()
+            tot_ms += st["kernel_ms"]; tot_fl += st["alg_flops"]; filled += int(r.filled_bases)
+            print(f"[config4] sub-batch {k}: {len(ids)} gaps, kernels {st['kernel_ms'] / 1e3:.1f} s", flush=True)
+        line = {"workload": f"{n_gaps} gaps as {(n_gaps + sub - 1) // sub} consecutive fills of ~{sub}", "kernel_ms": round(tot_ms, 1), "wall_s": round(time.time() - t0, 1),
+                "gaps_per_s": round(n_gaps / (tot_ms / 1e3), 2), "alg_tflops": round(tot_fl / 1e12 / (tot_ms / 1e3), 3),
+                "frac_of_fp64_nofma_peak": round(tot_fl / 1e12 / (tot_ms / 1e3) / 39.3, 4), "filled_bases": filled}
+        print("[config4] " + json.dumps(line), flush=True)
+        if out:
+            json.dump(line, open(out, "w"), indent=1)
+        eng.close()
+        return
     t0 = time.time(); eng.upload(batch); t_up = time.time() - t0
     print(f"[config4] packed + uploaded in {t_up:.1f} s", flush=True)
     # the fill is one blocking ABI call of several minutes: a heartbeat keeps the log moving meanwhile
