@@ -22,9 +22,13 @@ the line reports the counts actually run (`steps`, `warmup`) beside `requested_s
 One JSON line on stdout (rank 0), also when the budget runs out or the process receives SIGTERM."""
 from __future__ import annotations
 
+import os
 import time
 
 T_PROC0 = time.perf_counter()
+# one hardware queue per scheduler lane (up to nine streams per fill; the runtime's default is 4): must be in the environment
+# before the HIP runtime starts, i.e. before torch is imported -- see fig_ctx_create
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import argparse
 import json

@@ -278,6 +278,11 @@ extern "C" const char *fig_strerror(int code) {
 extern "C" int fig_ctx_create(int device_ordinal, fig_ctx **out) {
     if (!out) return FIG_EINVAL;
     *out = nullptr;
+    // A fill runs up to nine streams (one per class lane + the context's own); the HIP runtime maps streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (default 4), and two lanes' persistent kernels on one queue serialise.  Asking for 8
+    // is worth 1 % of the bench step.  Only effective when this is the process's first HIP call (figfill); a host that
+    // initialises HIP earlier sets the variable itself (bench.py and figfill_mp do).
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FIG_ENODEV;
     if (device_ordinal < 0 || device_ordinal >= n) return FIG_ENODEV;

@@ -23,6 +23,7 @@ from . import api, dist as fdist
 
 
 def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) -> int:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")      # one hardware queue per scheduler lane; before the HIP runtime starts (fig_ctx_create)
     import torch
     import torch.distributed as dist
 
