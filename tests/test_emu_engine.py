@@ -91,10 +91,10 @@ def test_emulated_split_class_lanes(tmp_path):
     split (FIGFILL_TRACE lists the launch classes)."""
     import numpy as np
     from figbird_amd import synth
-    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=5.0)
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=3.0, read_len=60, insert_mean=900.0, insert_sd=60.0, frag_len=60)
     mc = synth.bench_model_case(7, spec)
     rng = np.random.default_rng(97)
-    batch, _ = synth.make_bench_batch(97, 120, spec, gap_lengths=rng.integers(5, 26, size=120))
+    batch, _ = synth.make_bench_batch(97, 120, spec, gap_lengths=rng.integers(5, 16, size=120))
     outs = {}
     for who, exe in (("oracle", None), ("emu", util.EMU)):
         paths = synth.write_batch_subset(batch, list(range(120)), mc, str(tmp_path / who), spec)
