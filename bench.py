@@ -3,7 +3,9 @@
 BASELINE.json (SURVEY.md §8d recipe), with the FP64 roofline of the dominant kernel and the CPU baseline.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+  (N > 1 without a launcher: bench.py starts its own N ranks -- `python -m torch.distributed.run --nnodes=1
+   --nproc-per-node N --master-addr 127.0.0.1 ... bench.py <same args>` as a child process, before anything touches the GPU,
+   and relays the child's JSON line and exit code; under a launcher (WORLD_SIZE set) it is one of the ranks)
 
 Workload: the jump-library (unmapped-mode) fill pass -- the expensive iteration of RunFigbird.sh's schedule --
 over gaps drawn from the synthetic set's distribution: scaffolds of 50 kb with a gap every 5 kb, GAGE-like
@@ -12,9 +14,11 @@ at 3000 as Preprocess does), 0.5 % substitutions.  A bit-exact fill of the whole
 flops (hours on any hardware, CPU-years for the reference), so a "step" is one fill pass over a fixed seeded
 sample of `--gaps-per-gpu` x N gaps of that distribution, resident in HBM (`full_set_seconds_est` extrapolates).
 
-Multi-GPU (weak scaling): every rank generates the same global sample (same seed), the product's partitioner
+Multi-GPU: every rank generates the same global sample (same seed), the product's partitioner
 (figbird_amd.dist.partition_lpt on estimate_cost: the role of FillGaps.cpp:456-649) deals it into N shards, each rank
 fills its shard through the C ABI, and one all-gather of packed byte buffers per step reassembles the results.
+`--scaling weak` (default): the sample is `--gaps-per-gpu` x N gaps; `--scaling strong`: one fixed set of `--total-gaps`
+gaps whatever N is (BASELINE's metric is one 10^5-gap set at 1/2/4/8 GPUs; the default total is 8 x `--gaps-per-gpu`).
 
 Wall budget: the whole run (imports, generation, CPU baseline, partial pass, warm-up and timed steps) is kept
 inside `--budget-s` seconds.  The first fill is timed; warm-up and step counts are then clamped to what fits and
@@ -75,6 +79,38 @@ def _on_term(signum, frame):          # killed from outside: leave whatever has 
     os._exit(0 if "value" in OUT else 1)
 
 
+def launch_ranks(n, argv):
+    """`python bench.py --gpus N` with no launcher: run the N ranks as a child `torch.distributed.run` (one process per GPU,
+    rendezvous on 127.0.0.1), relay rank 0's JSON line, return the child's exit code.  The reference starts its own workers
+    the same way (FillGaps.cpp:668-679)."""
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC only on this pool (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "4")
+    env["FIGBENCH_T0_OFFSET"] = f"{time.perf_counter() - T_PROC0:.3f}"
+    print(f"[bench] no launcher: starting {n} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+
+    def _fwd(signum, frame):
+        child.send_signal(signum)
+    signal.signal(signal.SIGTERM, _fwd)
+    got = False
+    for ln in child.stdout:
+        if ln.lstrip().startswith("{"):
+            got = True
+        sys.stdout.write(ln); sys.stdout.flush()
+    rc = child.wait()
+    if rc != 0 or not got:
+        print(f"[bench] the {n}-rank child exited with code {rc}{'' if got else ' and printed no JSON line'}", file=sys.stderr, flush=True)
+        return rc or 1
+    return 0
+
+
 def workload_key(args, world):
     return f"{args.mode}|{args.mix}|g{args.gaps_per_gpu}|r{args.reads_per_gap:g}|s{args.seed}|n{world}"
 
@@ -94,7 +130,14 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--partial-pass", type=int, default=1, help="also report the partial-mode pass (untimed extra)")
     ap.add_argument("--cpu-sample-gaps", type=int, default=0, help="0 = five gaps per host core from the >400-bp bracket")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: gaps-per-gpu x N gaps; strong: one fixed set of --total-gaps")
+    ap.add_argument("--total-gaps", type=int, default=0, help="size of the fixed set of --scaling strong (0 = 8 x gaps-per-gpu)")
+    ap.add_argument("--bracket-probes", type=int, default=1, help="measure the cheap per-bracket probes inside this run (N=1 only)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # No launcher around us: start the N ranks ourselves.  Decided before torch / HIP are touched in this process, which
+        # stays a plain parent (it never initialises the GPU, the ranks are fresh child processes, nothing is exec'ed).
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
     signal.signal(signal.SIGTERM, _on_term)
 
     import torch
@@ -103,8 +146,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        log(f"warning: WORLD_SIZE={world} != --gpus {args.gpus}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libfighip has no CPU path")
     # Rehearsal knobs for a box with fewer GPUs than ranks (never set by the driver): FIGBENCH_DEVICE=<n> puts every rank on
@@ -121,10 +164,16 @@ def main():
             dist.init_process_group("nccl", device_id=gdev)
         else:
             dist.init_process_group(backend)
+        world = dist.get_world_size()          # n_gpus of the line = the ranks the process group reports
+        warm = torch.ones(1, device=dev)
+        dist.all_reduce(warm)                  # communicator set-up (RCCL builds its rings on the first collective) outside every timed region
+        assert int(warm.item()) == world
     log(f"imports + init done (budget {args.budget_s:.0f} s)")
 
+    t_parent = float(os.environ.get("FIGBENCH_T0_OFFSET", "0")) + (8.0 if "FIGBENCH_T0_OFFSET" in os.environ else 0.0)   # self-launched: parent + launcher start-up
+
     def left():
-        return args.budget_s - (time.perf_counter() - T_PROC0)
+        return args.budget_s - t_parent - (time.perf_counter() - T_PROC0)
 
     if args.mode == "unmapped":
         spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=args.reads_per_gap, gap_mix=args.mix)
@@ -140,7 +189,8 @@ def main():
                                  read_length=spec.read_len, neg_overlap=30, partial_len=mc.partial_len)
 
     # ---- the global sample (identical on every rank) and this rank's shard of it
-    gbatch, truth = synth.make_bench_batch(args.seed, args.gaps_per_gpu * world, spec)
+    n_set = (args.total_gaps or 8 * args.gaps_per_gpu) if args.scaling == "strong" else args.gaps_per_gpu * world
+    gbatch, truth = synth.make_bench_batch(args.seed, n_set, spec)
     n_global = gbatch.n_gaps
     off = gbatch.u_read_off if spec.mode == "unmapped" else gbatch.p_read_off
     cost = fdist.estimate_cost(np.asarray(gbatch.gap_len), np.diff(off), spec.read_len, spec.mode == "unmapped", mc.partial_len)
@@ -182,8 +232,9 @@ def main():
     OUT.update({
         "metric": "gaps/sec (+ filled-bases/sec), synthetic 1e5-gap set recipe, jump-library fill pass",
         "unit": "gaps/s", "n_gaps": n_global, "n_gpus": world, "requested_steps": args.steps, "requested_warmup": args.warmup,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-        "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, seeded sample of {args.gaps_per_gpu} gaps/GPU from the {args.mix} gap mix",
+        "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, seeded sample of "
+                               + (f"{args.gaps_per_gpu} gaps/GPU" if args.scaling == "weak" else f"{n_global} gaps in all (fixed set)") + f" from the {args.mix} gap mix",
                    "gaps_per_gpu": args.gaps_per_gpu, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
                    "insert": [spec.insert_mean, spec.insert_sd], "substitution_rate": spec.err,
                    "sharding": f"{n_global} gaps dealt LPT on estimated cost over {world} rank(s), no data-path collective, 1 all-gather of packed results per step"},
@@ -218,6 +269,15 @@ def main():
         except Exception as e:  # pragma: no cover
             OUT["partial_pass"] = {"value": None, "unit": "gaps/s", "note": f"failed: {e!r}"}
         extras_s += time.perf_counter() - t
+
+    if rank == 0 and world == 1 and args.mode == "unmapped" and args.bracket_probes and left() > 2.5 * t_first + 40:
+        t = time.perf_counter()
+        try:
+            OUT["per_bracket"] = bracket_probes(args, eng, batch, spec, min(45.0, left() - 2.5 * t_first - 10))
+        except Exception as e:  # pragma: no cover
+            OUT["per_bracket"] = {"note": f"failed: {e!r}"}
+        extras_s += time.perf_counter() - t
+        log(f"bracket probes done in {time.perf_counter() - t:.1f} s")
 
     # ---- clamp warm-up and steps to what is left (10 s reserve for teardown); timed steps come first
     left_min = -allmax(-left())                       # the rank with the least budget left decides
@@ -282,6 +342,17 @@ def main():
                 "frac": alg_bytes / max(ksec, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg_bytes / steps,
                 "note": "path is FP64-ALU bound (~1e5-1e7 flop/byte); HBM figure reported because the north star asks for it"}}
     if st.get("spec_flops", 0) > 0 and st.get("mle_alg_flops", 0) > 0:
+        # LDS is the roof that binds the pair-chain form of the E-step: 16 B of table per chain step (4 flops) and
+        # 8 B of weight row per pile-up add.  chain steps S = the MLE term (1 flop per step), adds A = alg - 5 S.
+        S_steps = st["mle_alg_flops"] * (st["alg_flops"] / st["spec_flops"])
+        A_adds = max(0.0, st["alg_flops"] - 5.0 * S_steps)
+        lds_bytes = 16.0 * S_steps + 8.0 * A_adds
+        lds_peak = 256 * 256 * 2.4e9                         # 256 CUs x 256 B/clk x 2.4 GHz
+        step_ksec = st["kernel_ms"] / 1e3
+        OUT["roofline"]["lds"] = {"bytes_per_step_pair_chain_form": lds_bytes, "peak": lds_peak / 1e12, "unit": "TB/s",
+                                  "achieved": lds_bytes / max(step_ksec, 1e-12) / 1e12, "frac": lds_bytes / max(step_ksec, 1e-12) / lds_peak,
+                                  "note": "LDS bytes the one-table-read-per-chain-step form needs (16 B per E-step chain step + 8 B per pile-up add), last step, vs 256 CU x 256 B/clk; "
+                                          "an E-step that shares the per-column factors between the reads of a chunk needs fewer (DESIGN §4a)"}
         # credited flops the device really executed: everything but the pruned part of the MLE term (ratios taken over all
         # evaluations of the last step, discarded speculation included)
         mle_share = st["mle_alg_flops"] / st["spec_flops"]
@@ -305,10 +376,36 @@ def main():
         import torch.distributed as dist
         dist.destroy_process_group()
     if rank == 0 and args.mode == "unmapped":
-        OUT["per_bracket"] = read_brackets()
+        OUT.setdefault("per_bracket", {})["from_file"] = read_brackets()
     OUT["fills_run"] = warm_done + warm_more + steps        # fills of the main batch (what a profiler around this command sees)
     OUT["wall_s_total"] = time.perf_counter() - T_PROC0
     emit()
+
+
+def bracket_probes(args, eng, main_batch, spec, budget_s):
+    """Per-bracket figures measured in THIS run (gaps/s per bracket beside the blended number): batches of equal
+    gaps at ~1000 reads each, kernel time of one fill on the resident batch.  Only the cheap brackets fit the wall budget
+    (one-candidate gaps > 400 bp, and a 64-gap probe of the <= 400-bp regime); the rest is read from the committed probe."""
+    from figbird_amd import synth
+    t0 = time.perf_counter()
+    rows = []
+    eng.free_batch()
+    try:
+        for G, n in ((800, 256), (1500, 256), (1800, 256), (2000, 256), (100, 64)):
+            if time.perf_counter() - t0 > budget_s * (0.6 if G > 400 else 0.35):
+                rows.append({"gap_bp": G, "note": "skipped: probe budget spent"})
+                continue
+            b, _ = synth.make_bench_batch(args.seed + G, n, synth.BenchSpec(mode="unmapped", reads_per_gap_mean=1000.0), gap_lengths=np.full(n, G))
+            eng.upload(b)
+            eng.fill_resident()
+            st = eng.stats()
+            eng.free_batch()
+            ks = max(st["kernel_ms"] / 1e3, 1e-9)
+            rows.append({"gap_bp": G, "n_gaps": n, "reads_per_gap": float(b.u_read_off[-1]) / n, "gaps_per_s": n / ks, "kernel_s": ks,
+                         "tflops": st["alg_flops"] / ks / 1e12, "frac_of_fp64_nofma_peak": st["alg_flops"] / ks / 1e12 / FP64_NOFMA_PEAK_TFLOPS})
+    finally:
+        eng.upload(main_batch)
+    return {"measured_in_this_run": rows, "note": "batches of equal gaps, ~1000 reads each, kernel time of one fill; 256 gaps fill every CU once for the one-candidate brackets; the 64-gap 100-bp probe runs 64 gaps x ~270 candidates through the scheduler"}
 
 
 def read_brackets():
@@ -340,7 +437,14 @@ def read_traffic(args, world):
             if e1:
                 return e1["bytes_per_step"] * world, e1.get("note", "") + f" x {world} ranks, scaled from the 1-GPU PMC pass (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
         if ent:
-            return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
+            stale = ""
+            try:
+                head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
+                if head and sc.get("head") and head != sc.get("head"):
+                    stale = f"; STALE: recorded at head {sc.get('head')}, this is {head}"
+            except Exception:
+                pass
+            return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')}{stale})"
         return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"
     except Exception as e:
         return None, f"profiles/traffic_sidecar.json unreadable: {e!r}"

@@ -40,14 +40,27 @@ def estimate_cost(gap_len: np.ndarray, n_reads: np.ndarray, read_len: int, unmap
     return R * W * read_len * np.maximum(cand, 1.0) * its + 1.0
 
 
-def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None, extras: Sequence[np.ndarray] = ()):
+def all_status_max(code: int, device=None) -> int:
+    """MAX over ranks of a small status code (0 = fine): every rank learns that some rank failed BEFORE the payload
+    collective, so that all of them leave together instead of one returning early and the others blocking in all_gather."""
+    import torch
+    import torch.distributed as dist
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return int(code)
+    t = torch.tensor([int(code)], dtype=torch.int32, device=device if device is not None else torch.device("cpu"))
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
+def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None, extras: Sequence[np.ndarray] = (), force_collective: bool = False):
     """All-gather the shard results as packed byte buffers: one small header exchange, then ONE all-gather of a
     single uint8 buffer per rank laid out [ids | filled_len | gaptofill | extras... | gap strings], straight from the
     numpy arrays the C ABI filled (no per-gap Python strings on the way).  `res` is an api.FillResult (fields
     filled_len, gaptofill, str_off, raw); `extras` are optional int32 arrays of any length that travel with the
     shard (figfill_mp sends the draw planes this way).  Returns (filled_len[n_total], gaptofill[n_total], strings)
     -- `strings` a PackedStrings in global gap order -- and, when extras were given, a fourth element: per rank,
-    the tuple (ids, extras...) as received."""
+    the tuple (ids, extras...) as received.  A single rank skips the collective unless `force_collective` (a one-rank RCCL
+    run of the device-tensor path: tests/test_gpu_parity.py)."""
     import torch
     import torch.distributed as dist
 
@@ -60,7 +73,7 @@ def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None, extras
     payload = np.ascontiguousarray(res.raw[:nbytes], dtype=np.uint8)
     ex = [np.ascontiguousarray(e, dtype=np.int32) for e in extras]
     ne = len(ex)
-    if world == 1:
+    if world == 1 and not (force_collective and dist.is_initialized()):
         blobs = [(ids_a, fl_a, gt_a, payload, ex)]
     else:
         dev = device if device is not None else torch.device("cpu")

@@ -1,7 +1,8 @@
 """figfill over N GPUs of one node -- the multi-GPU face of the FillGaps.cpp drop-in.
 
+    python -m figbird_amd.figfill_mp --gpus N <the 15 FillGaps arguments>          (starts its own N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \\
-        -m figbird_amd.figfill_mp <the 15 FillGaps arguments>
+        -m figbird_amd.figfill_mp <the 15 FillGaps arguments>                       (under a launcher)
 
 One process per GPU.  Every rank opens the run through libfighost (same inputs, same model, built once per rank as the
 reference builds it once per thread), the gap set is dealt into N shards by `dist.partition_lpt` on `dist.estimate_cost`
@@ -46,6 +47,11 @@ def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) ->
     h = host.fighost_run_open(args, err, 512)
     if not h:
         sys.stderr.write(err.value.decode() + "\n")
+    if fdist.all_status_max(0 if h else 1, dev) != 0:        # every rank leaves together (a peer must not wait in the all-gather)
+        if h:
+            host.fighost_run_close(h)
+        if own_pg:
+            dist.destroy_process_group()
         return 1
     try:
         n = int(host.fighost_run_ngaps(h))
@@ -65,13 +71,20 @@ def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) ->
         rc = host.fighost_run_shard(h, api._p(mine if len(mine) else np.zeros(1, dtype=np.int64), api.c_i64_p), len(mine), C.byref(cb), C.byref(su), C.byref(sp))
         if rc != 0:
             sys.stderr.write("figfill_mp: bad shard\n")
-            return 1
-        eng = api.Engine(local, lib_path=lib_path)
-        eng.set_model_struct(cm)
+        res = st = None
         tk = time.time()
-        res = eng.fill_struct(cb, int(su.value), int(sp.value), draw=True)
-        st = eng.stats()
-        eng.close()
+        if rc == 0:
+            try:
+                eng = api.Engine(local, lib_path=lib_path)
+                eng.set_model_struct(cm)
+                res = eng.fill_struct(cb, int(su.value), int(sp.value), draw=True)
+                st = eng.stats()
+                eng.close()
+            except Exception as e:       # e.g. FIG_ENOMEM on one GPU: reported to every rank below
+                sys.stderr.write(f"figfill_mp: rank {rank}: {e}\n")
+                rc = 1
+        if fdist.all_status_max(rc, dev) != 0:
+            return 1
         dpos, disz, dlen = res.draw
         out = fdist.all_gather_packed(mine, res, n, device=dev, extras=[dlen, dpos, disz])
         fl, gt, ps, per_rank = out
@@ -101,29 +114,54 @@ def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) ->
                                         api._p(g_pos, api.c_i32_p), api._p(g_isz, api.c_i32_p), api._p(g_len, api.c_i32_p), err, 512)
             if rc != 0:
                 sys.stderr.write(err.value.decode() + "\n")
-                return 1
-            if verbose:
+            wrc = rc
+            if rc == 0 and verbose:
                 print(f"Time taken = {time.time() - t0:g} seconds ({world} rank(s); rank 0: {len(mine)} gaps, device kernels {st['kernel_ms']:.3f} ms, fill {time.time() - tk:.3f} s)")
                 print("======================================")
                 print(f"Iteration {int(argv15[3])} ends successfully")
                 print("======================================")
-        if world > 1:
-            dist.barrier()
-        return 0
+        else:
+            wrc = 0
+        return 1 if fdist.all_status_max(wrc, dev) != 0 else 0        # doubles as the closing barrier
     finally:
         host.fighost_run_close(h)
         if own_pg:
             dist.destroy_process_group()
 
 
+def launch_ranks(n: int, argv15) -> int:
+    """`--gpus N` without a launcher: run the N ranks as a child `torch.distributed.run` (the reference starts its own
+    workers too, FillGaps.cpp:668-679).  This parent never touches the GPU; it returns the child's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), "-m", "figbird_amd.figfill_mp"] + list(argv15)
+    return subprocess.call(cmd, env=env)
+
+
 def main():
+    if len(sys.argv) >= 3 and sys.argv[1] == "--gpus":
+        n = int(sys.argv[2])
+        del sys.argv[1:3]
+        if n > 1 and "WORLD_SIZE" not in os.environ:
+            if len(sys.argv) < 16:
+                sys.stderr.write("figfill_mp: --gpus N needs the 15 FillGaps arguments\n")
+                sys.exit(1)
+            sys.exit(launch_ranks(n, sys.argv[1:16]))
     if len(sys.argv) < 16:
         sys.stderr.write("usage: [torchrun ...] -m figbird_amd.figfill_mp <contigs.fa> <maxDistance> <readLen> <scriptItr> <partialFlag> <unmapped> "
                          "<numThreads> <myout.sam> <tmp/> <gaps/> <negOverlap> <partialReadLen> <trim> <setInputMean> <insertSize>\n")
         sys.exit(1)
-    # FIGFILL_DEVICE=<n>: every rank on GPU n; FIGFILL_MP_BACKEND=gloo: host-side all-gather (rehearsal on a box with fewer GPUs
-    # than ranks -- RCCL refuses two ranks on one device)
-    dev = os.environ.get("FIGFILL_DEVICE")
+    # FIGFILL_MP_DEVICE=<n>: every rank on GPU n; FIGFILL_MP_BACKEND=gloo: host-side all-gather (rehearsal on a box with fewer
+    # GPUs than ranks -- RCCL refuses two ranks on one device).  figfill's own selector FIGFILL_DEVICE is deliberately NOT read
+    # here: left exported, it would pin every rank of a real multi-GPU run to one card.
+    dev = os.environ.get("FIGFILL_MP_DEVICE")
     sys.exit(run(sys.argv[1:16], backend=os.environ.get("FIGFILL_MP_BACKEND"), device_index=int(dev) if dev is not None else None))
 
 

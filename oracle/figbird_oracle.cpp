@@ -18,7 +18,7 @@
 // Usage (same positional arguments as the reference programs):
 //   figbird_oracle figbird  <16 args of Figbird.cpp main, Figbird.cpp:6957-6973>
 //   figbird_oracle fillgaps <15 args of FillGaps.cpp main, FillGaps.cpp:419-433>
-// Env: FIG_ORACLE_TRACE=<file> FIG_ORACLE_TRACE_LEVEL=1|2|3 -> per-candidate / per-iteration
+// Env: FIG_ORACLE_TRACE=<file> FIG_ORACLE_TRACE_LEVEL=1|2|3|4 -> per-candidate / per-iteration
 //      numeric planes (hex floats) used as kernel-parity fixtures.
 #include <algorithm>
 #include <cfloat>
@@ -43,6 +43,24 @@ const int windowSize = 12;          // Figbird.cpp:89
 
 FILE *g_trace = nullptr;
 int g_trace_level = 0;
+// Trace level 4 = level 3 with the E/R plane records of a candidate held back until its CAND line, so that only the planes
+// of the LAST E-step of every candidate reach the file (level 3 writes them after every EM iteration: hundreds of MB for a
+// bench-regime gap).  The planes go to an in-memory stream that is rewound at every E-step.
+char *g_plane_buf = nullptr;
+size_t g_plane_len = 0;
+FILE *g_plane_mem = nullptr;
+FILE *trace_plane_file() {
+    if (g_trace_level < 4) return g_trace;
+    if (g_plane_mem) { fclose(g_plane_mem); free(g_plane_buf); g_plane_buf = nullptr; }
+    g_plane_mem = open_memstream(&g_plane_buf, &g_plane_len);
+    return g_plane_mem;
+}
+void trace_plane_flush() {
+    if (!g_plane_mem) return;
+    fclose(g_plane_mem); g_plane_mem = nullptr;
+    fwrite(g_plane_buf, 1, g_plane_len, g_trace);
+    free(g_plane_buf); g_plane_buf = nullptr;
+}
 long g_place_calls = 0;
 double g_flops = 0;                 // algorithmic FP64 flops: 4 per E-step base, 1 per MLE base, 1 per countsGap add
 
