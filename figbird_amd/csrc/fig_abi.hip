@@ -34,7 +34,7 @@
 #endif
 // MLE-pass accounting (raw totals incl. discarded speculation; only their ratio is reported): [3] credited, [4] executed
 #define FIG_FLUSH_MLE() do { if (E.mle_alg) atomicAdd(&B.counters[3], E.mle_alg); if (E.lane == 0 && E.mle_exec) atomicAdd(&B.counters[4], E.mle_exec); } while (0)
-struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel, tiles, tile_step, tile_cols, tiled_max; };
+struct FigKernArgs { int capG, capGl, ncolE, Wcap, nteams, q_begin, q_end, qsel, tiles, tile_step, tile_cols, tiled_max, sh_on; };
 
 FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, const FigKernArgs &A, bool lds_tab, FigScr &work) {
     E.tid = threadIdx.x; E.nt = blockDim.x;
@@ -42,7 +42,7 @@ FIG_D void fig_eng_init(FigEng &E, const FigDevModel &M, const FigDevBatch &B, c
     E.M = &M; E.B = &B;
     E.capG = A.capG; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0;
     for (int i = 0; i < 40; i++) E.prof[i] = 0;
-    E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams;
+    E.ncolE = A.ncolE; E.xoff = M.L - 1; E.Wcap = A.Wcap; E.nteams = A.nteams; E.sh_on = A.sh_on;
     unsigned char *slab = B.scratch + (long long)blockIdx.x * B.scratch_stride;
     fig_scratch_layout(slab, B.capG, B.capR, B.capP, B.capC, B.capW, B.capE, &work);
     E.scr = work;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) fig_replay_kernel(FigDevModel M, FigDevBat
     FigEng E; FigScr work;
     memset(&work, 0, sizeof(work));
     E.tid = threadIdx.x; E.nt = blockDim.x; E.lane = threadIdx.x & 63; E.wave = 0; E.nw = 1; E.wsz = 64;
-    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1;
+    E.M = &M; E.B = &B; E.capG = 0; E.flops = 0; E.mle_alg = 0; E.mle_exec = 0; E.wait_cycles = 0; E.ncolE = 0; E.xoff = 0; E.Wcap = 0; E.nteams = 1; E.sh_on = 0;
     E.pq = nullptr; E.q4 = nullptr; E.wbuf = nullptr; E.gs = nullptr; E.rb = nullptr; E.plb = nullptr; E.off_plb = 0; E.pq_lds = 0; E.w_lds = 0;
     E.off_pq = E.off_q4 = E.off_w = 0; E.tiles = E.tile_step = E.tile_cols = 0; E.lds_tw = 0;
     E.S = (FigState *)fig_lds;
@@ -195,6 +195,39 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_end_kernel(FigDev
     }
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
     FIG_FLUSH_MLE();
+}
+
+// ---- upload-time kernel: the operand-select stream of the shared-factor E-step (fig_engine_shared.h).  Entry (read r, chain
+// step j) = 0x1000 | 2 * (4 * reverse + base_j): the value M0 takes so that `v_mul_f64 p, v[F0:F0+1], p` in VGPR-index mode
+// multiplies by the factor f[orientation][base].  Reads the fast path cannot take (an N base, a length other than L) and the
+// empty slots of a gap's last chunk select the constant 1.0.  Layout per gap: [chunk of 32 reads][step][32 reads] 16-bit
+// entries, two per dword.  One block per gap.
+__global__ void __launch_bounds__(256) fig_stream_kernel(FigDevModel M, FigDevBatch B, uint32_t *out) {
+    for (long long gi = blockIdx.x; gi < B.n_gaps; gi += gridDim.x) {
+        const FigDevGap &g = B.gaps[gi];
+        const int L = M.L;
+        const long long n = (long long)((g.nU + FIG_SH_C - 1) / FIG_SH_C) * L * (FIG_SH_C / 2);
+        for (long long i = threadIdx.x; i < n; i += blockDim.x) {
+            const int sp = (int)(i % (FIG_SH_C / 2));
+            const long long cj = i / (FIG_SH_C / 2);
+            const int j = (int)(cj % L);
+            uint32_t v = 0;
+            for (int h = 0; h < 2; h++) {
+                const long long r = (cj / L) * FIG_SH_C + 2 * sp + h;
+                unsigned e = 0x1000u | FIG_SH_ONE;
+                if (r < g.nU) {
+                    const long long idx = g.uBase + r;
+                    const int len = B.u.len[idx], aux = B.u.aux[idx];
+                    if (len == L && !(aux & 2)) {
+                        const uint32_t w = B.packed[B.u.woff[idx] + (j >> 4)];
+                        e = 0x1000u | (2u * (4u * (unsigned)(aux & 1) + ((w >> ((j & 15) * 2)) & 3u)));
+                    }
+                }
+                v |= e << (16 * h);
+            }
+            out[g.streamOff + i] = v;
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------- context
@@ -436,6 +469,12 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
 #undef UP
     db.u.clip = nullptr; db.u.refpos = nullptr; db.u.qoff = nullptr;
     void *p;
+    if (m->unmapped_flag) {
+        if ((rc = dev_alloc(ctx, (size_t)K.stream_total * 4, &p))) return rc;
+        db.ustream = (const uint32_t *)p;
+        FIG_HIP(hipMemsetAsync(p, 0, (size_t)K.stream_total * 4, ctx->stream));
+        if (ng > 0) hipLaunchKernelGGL(fig_stream_kernel, dim3((unsigned)std::min<int64_t>(ng, 4096)), dim3(256), 0, ctx->stream, ctx->dm, db, (uint32_t *)p);
+    }
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.filled_len = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)str_total, &p))) return rc; db.str = (char *)p;
@@ -483,6 +522,7 @@ static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
     A.q_begin = c.c.q_begin; A.q_end = c.c.q_end; A.qsel = 0;
     A.tiles = c.c.tiles; A.tile_step = c.c.tile_step; A.tile_cols = c.c.tile_cols; A.tiled_max = c.c.tiled_max;
+    { const char *ev = getenv("FIG_ESTEP"); A.sh_on = !(ev && !strcmp(ev, "pair")); }      // FIG_ESTEP=pair: the pair-chain E-step everywhere (A/B runs, tests)
     return A;
 }
 

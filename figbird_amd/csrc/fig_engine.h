@@ -148,6 +148,9 @@ struct FigState {
     int tm_lo[16], tm_hi[16], tm_len[16], tm_tis0[16], tm_dir[16];
     int tm_aux[16]; long long tm_woff[16];   // LDS-tiled class: the chunk's read scalars, staged once per chunk
     double wv_v[32]; int wv_o[32];   // per-wave partial arg-max ([team][wave of the team]; LDS-tiled class: [read of the chunk][wave])
+    // shared-factor E-step (fig_engine_shared.h): insert-size windows of the chunk's 32 reads; reads that take the generic chain
+    int sh_lo[FIG_SH_C], sh_hi[FIG_SH_C], sh_tis0[FIG_SH_C], sh_dir[FIG_SH_C], sh_len[FIG_SH_C], sh_aux[FIG_SH_C]; long long sh_woff[FIG_SH_C];
+    unsigned sh_irr, sh_pad;
     int mle_next, pad_mn;            // next read of the MLE pass (waves take reads dynamically)
     int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics
     FigLoop L;
@@ -263,6 +266,7 @@ struct FigEng {
     int tiles, tile_step, tile_cols; // > 0: the table lives in HBM/L2 (pq, q4) and the E-step streams it through an LDS tile at off_pq / off_q4
     double *wbuf;                    // [nteams][Wcap]
     int Wcap, nteams;
+    int sh_on;                       // the shared-factor E-step may be used (FIG_ESTEP=pair switches it off)
     int lane, wave, nw, wsz;         // lane in wave, wave in workgroup, waves per workgroup, lanes per wave
     const double *kt_fwd, *kt_rev;   // {1-e[k], e[k]} pairs, forward and reversed (index (L-len)+j), for scalar loads
     const double *mt_fwd, *mt_rev;   // {1-e-ins-del, e[k]} pairs for the MLE pass

@@ -844,6 +844,8 @@ FIG_NOINLINE FIG_D void fig_hot_estep(FigEng &E, int gapoffset) {
     FIG_SYNC();
 }
 
+#include "fig_engine_shared.h"
+
 template <bool LDS>
 FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
 #ifdef FIG_EMU
@@ -860,6 +862,19 @@ FIG_D void fig_hot_estep_dispatch(FigEng &E, int gapoffset) {
         else if (cpl <= 24) fig_hot_estep<LDS, 24, true>(E, gapoffset);          // gaps of 2049-3072 bp
         else if (cpl <= 32) fig_hot_estep<LDS, 32, true>(E, gapoffset);          // ... -4096 bp
         else fig_hot_estep<LDS, 0, true>(E, gapoffset);
+        return;
+    }
+    if (LDS && fig_sh_applies(E, cpl)) {
+        switch (cpl) {
+            case 1: fig_hot_estep_sh<1>(E, gapoffset); break;
+            case 2: fig_hot_estep_sh<2>(E, gapoffset); break;
+            case 3: fig_hot_estep_sh<3>(E, gapoffset); break;
+            case 4: fig_hot_estep_sh<4>(E, gapoffset); break;
+            case 5: fig_hot_estep_sh<5>(E, gapoffset); break;
+            case 6: fig_hot_estep_sh<6>(E, gapoffset); break;
+            case 7: fig_hot_estep_sh<7>(E, gapoffset); break;
+            default: fig_hot_estep_sh<8>(E, gapoffset); break;
+        }
         return;
     }
     switch (cpl) {

@@ -1,0 +1,423 @@
+// fig_engine_shared.h -- the shared-factor form of the unmapped E-step's placement phase (gfx950 only).
+//
+// The per-base factor of placeReads' E-step product (Figbird.cpp:3559-3589)
+//        f = probs[x][b] * (1 - e[k]) + e[k] * errorProbs[x][b],        x = o + j,  b = read base j,  k = j or L-1-j
+// does not depend on the READ, only on (column x, chain step j, orientation, base): every read of the gap that puts base b at
+// step j of placement o multiplies by the same double.  The pair-chain form (fig_hot_estep) recomputes it per (read,
+// placement, step): 4 FP64 operations and 16 B of LDS per step.  Here a lane owns ONE placement o and carries the products
+// of a whole CHUNK of 32 reads; per chain step it fetches the column's {P,Q}[0..3] once (64 B), computes the eight factors
+// f[orientation][base] once (24 operations: the same multiply, multiply, add as the reference, so the same bits) and every
+// read's product takes the factor its own base selects with ONE multiply:  (24 + 32) / 32 = 1.75 operations and 2 B of LDS
+// per (read, placement, step) instead of 4 and 16.
+//
+// The select is wave-uniform (all lanes of a wave work on the same reads) but differs per read and step, so it is a
+// register-file index, not a branch: the eight factors sit in v[232:247], the constant 1.0 in v[248:249], the wave runs in
+// VGPR-index mode (s_set_gpr_idx_on ... SRC0) and per multiply ONE SALU instruction moves the next 16-bit entry of the
+// gap's operand-select stream (fig_stream_kernel: 0x1000 | 2 * (4 * reverse + base)) into M0.  One SALU instruction per
+// multiply is what the CU's scalar unit sustains beside the FP64 pipe (a 4-bit stream that needed two was scalar-bound);
+// SALU and VALU issue from the two waves of a SIMD side by side; measured (tools/ubench/idx2.hip) the indexed multiplies
+// cost what plain ones do.
+//
+// Work split of a chunk: tiles of 64 consecutive placements; wave w takes tiles w, w + nw, ... with all 32 reads; the tiles
+// left over by the last full round are split over the waves by READS (32/f reads each) so that no wave idles.  The finished
+// weights stay in registers (two banks of 32 doubles per lane) and go to the LDS weight rows four reads at a time, where
+// the unchanged column pass adds them in the reference's (read, placement) order.  Reads the stream cannot describe (an N
+// base, a length other than L) take the generic chain of fig_engine_hot.h inside their row group.
+#ifndef FIG_ENGINE_SHARED_H
+#define FIG_ENGINE_SHARED_H
+#ifndef FIG_EMU
+#define FIG_FI __device__ static __forceinline__
+
+// ---- wave maximum of a non-negative double through its bit pattern (positive doubles order like their 64-bit integers):
+// v_max_u32 with DPP row shifts / broadcasts on the high words, then on the low words of the lanes that hold the maximal
+// high word.  Result in every lane (hi, lo).
+FIG_D unsigned fig_wave_max_u32(unsigned v) {
+#define FIG_DPP_UMAX(ctrl, rmask) do { const unsigned y_ = (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rmask, 0xf, false); v = y_ > v ? y_ : v; } while (0)
+    FIG_DPP_UMAX(0x111, 0xf); FIG_DPP_UMAX(0x112, 0xf); FIG_DPP_UMAX(0x114, 0xf); FIG_DPP_UMAX(0x118, 0xf);
+    FIG_DPP_UMAX(0x142, 0xa); FIG_DPP_UMAX(0x143, 0xc);
+#undef FIG_DPP_UMAX
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+
+// ---- the indexed multiplies.  F0..F7 and the constant 1.0 are pinned to v[232:249]; p* are the products (any registers);
+// w* hold two 16-bit entries of the operand-select stream each: the value M0 takes (0x1000 = "SRC0 is indexed" | register
+// offset 2 * (4 * reverse + base), or 16 = the 1.0 for a slot without a regular read).  Per multiply ONE SALU instruction.
+#define FIG_SH_M2(pa, pb, w) \
+    "s_and_b32 m0, " w ", 0xffff\n v_mul_f64 " pa ", v[232:233], " pa "\n" \
+    "s_lshr_b32 m0, " w ", 16\n v_mul_f64 " pb ", v[232:233], " pb "\n"
+#define FIG_SH_FIN "{v[232:233]}"(f[0]), "{v[234:235]}"(f[1]), "{v[236:237]}"(f[2]), "{v[238:239]}"(f[3]), "{v[240:241]}"(f[4]), \
+                   "{v[242:243]}"(f[5]), "{v[244:245]}"(f[6]), "{v[246:247]}"(f[7]), "{v[248:249]}"(one)
+FIG_FI void fig_sh_mul4(double *p, const double *f, double one, const uint32_t *w) {
+    asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]") "s_set_gpr_idx_off\n"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]) : "scc");
+}
+FIG_FI void fig_sh_mul8(double *p, const double *f, double one, const uint32_t *w) {
+    asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
+                 FIG_SH_M2("%[p4]", "%[p5]", "%[w2]") FIG_SH_M2("%[p6]", "%[p7]", "%[w3]") "s_set_gpr_idx_off\n"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7])
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]) : "scc");
+}
+FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t *w) {
+    asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
+                 FIG_SH_M2("%[p4]", "%[p5]", "%[w2]") FIG_SH_M2("%[p6]", "%[p7]", "%[w3]") FIG_SH_M2("%[p8]", "%[p9]", "%[w4]")
+                 FIG_SH_M2("%[p10]", "%[p11]", "%[w5]") FIG_SH_M2("%[p12]", "%[p13]", "%[w6]") FIG_SH_M2("%[p14]", "%[p15]", "%[w7]") "s_set_gpr_idx_off\n"
+                 : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]),
+                   [p8] "+v"(p[8]), [p9] "+v"(p[9]), [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p15] "+v"(p[15])
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]), [w4] "s"(w[4]), [w5] "s"(w[5]), [w6] "s"(w[6]), [w7] "s"(w[7])
+                 : "scc");
+}
+
+// ---- the chain: NS products per lane over the L steps of the chunk.  colp = PQ + x (x = o + xoff: the lane's first column),
+// st = the chunk's stream row of step 0 at this wave's first slot (16 dwords per step; one padded row behind the last).
+// The loads of step j + 1 (four ds_read_b128, the stream row, the {1-e, e} pairs of both orientations) are issued before
+// the arithmetic of step j.  (A scalar load that misses the scalar cache comes back from L2 in ~190 cycles against ~135 on
+// a hit, tools/ubench/kcache.hip: one step of arithmetic covers either.)
+template <int NS>
+FIG_FI void fig_sh_chain(double (&p)[FIG_SH_C], const FigPQ *colp, int ncolE, fig_cu32p st, fig_cdp ktf, fig_cdp ktr, int L) {
+    uint32_t wn[NS / 2];
+    double kn[4];
+    FigPQ an[4];
+#pragma unroll
+    for (int k = 0; k < NS / 2; k++) wn[k] = st[k];
+    kn[0] = ktf[0]; kn[1] = ktf[1]; kn[2] = ktr[0]; kn[3] = ktr[1];
+#pragma unroll
+    for (int b = 0; b < 4; b++) an[b] = colp[b * ncolE];
+    const double one = 1.0;
+    for (int j = 0; j < L; j++) {
+        uint32_t w[NS / 2];
+        double kk[4];
+        FigPQ a[4];
+#pragma unroll
+        for (int k = 0; k < NS / 2; k++) w[k] = wn[k];
+#pragma unroll
+        for (int k = 0; k < 4; k++) { kk[k] = kn[k]; a[k] = an[k]; }
+        {
+            fig_cu32p sn = st + (j + 1) * (FIG_SH_C / 2);
+#pragma unroll
+            for (int k = 0; k < NS / 2; k++) wn[k] = sn[k];
+            kn[0] = ktf[2 * j + 2]; kn[1] = ktf[2 * j + 3]; kn[2] = ktr[2 * j + 2]; kn[3] = ktr[2 * j + 3];
+            const FigPQ *cn = colp + (j + 1);
+#pragma unroll
+            for (int b = 0; b < 4; b++) an[b] = cn[b * ncolE];
+        }
+        double f[8];
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            f[b] = a[b].p * kk[0] + kk[1] * a[b].q;           // forward reads: {1-e[j], e[j]}          (:3581-3589)
+            f[4 + b] = a[b].p * kk[2] + kk[3] * a[b].q;       // reverse reads: {1-e[L-1-j], e[L-1-j]}  (:3569-3576)
+        }
+        if (NS == 32) { fig_sh_mul16(&p[0], f, one, &w[0]); fig_sh_mul16(&p[16], f, one, &w[8]); }
+        else if (NS == 16) fig_sh_mul16(&p[0], f, one, &w[0]);
+        else if (NS == 8) fig_sh_mul8(&p[0], f, one, &w[0]);
+        else fig_sh_mul4(&p[0], f, one, &w[0]);
+    }
+}
+
+// One unit = (tile of 64 placements, NS reads [s0, s0 + NS) of the chunk): products start from the insert-size terms
+// (1.0 for a placement outside the read's window: never used), run the chain and go to the workgroup's product rows in the
+// scratch slab, prow[s * pst + (o + L - 1)] (coalesced 512-byte stores; read back four reads at a time by phase B).
+// Lanes past the last placement (vo false) run on the tile's first placement and store nothing.
+template <int NS>
+FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ *PQ, fig_cu32p stream, double *prow, const int pst, const int o, const bool vo, const int ocalc) {
+    double p[FIG_SH_C];
+#pragma unroll
+    for (int i = 0; i < NS; i++) {
+        const int s = s0 + i;
+        const int lo = fig_u(S.sh_lo[s]), hi = fig_u(S.sh_hi[s]), tis0 = fig_u(S.sh_tis0[s]), dir = fig_u(S.sh_dir[s]);
+        p[i] = 1.0;
+        if (ocalc >= lo && ocalc <= hi) p[i] = U.insd[tis0 + dir * ocalc];
+    }
+    fig_sh_chain<NS>(p, PQ + (ocalc + U.xoff), U.ncolE, stream + (s0 >> 1), (fig_cdp)U.kt_fwd, (fig_cdp)U.kt_rev, U.L);
+    if (vo) {
+        double *dst = prow + (long long)s0 * pst + (o + U.L - 1);
+#pragma unroll
+        for (int i = 0; i < NS; i++) dst[(long long)i * pst] = p[i];
+    }
+}
+
+// ---- the E-step with the shared-factor placement phase.  Same contract as fig_hot_estep<LDS = true, CPL, TILED = false>.
+template <int CPL>
+FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
+    constexpr bool LDS = true;
+    constexpr int NR = 4;                                      // weight rows per group of the column pass (the class has >= 4)
+    constexpr int KP = 2;                                      // placements per thread and row in phase B: Wn <= KP * nt (dispatcher)
+    FigState &S = *E.S;
+    const FigHotU U = fig_hot_uniforms(E);
+    const int G = U.G, nU = U.nU, cg = U.cg;
+    const long long ub = U.ub;
+    const FigPQ *PQ = fig_pq_ptr<LDS>(E);
+    double *W = fig_w_ptr<LDS>(E);
+    const int Wcap = U.Wcap;
+    const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid, nw = U.nw;
+    const fig_cu32p stream0 = (fig_cu32p)(fig_uptr(fig_uptr(E.B)->ustream) + fig_u64(fig_uptr(E.g)->streamOff));
+    double *prow = fig_uptr(E.scr.wg);                        // raw products of the chunk: [32 reads][pst] (scratch slab, L2)
+    const int pst = Wcap;
+    double acc[CPL];
+#pragma unroll
+    for (int m = 0; m < CPL; m++) acc[m] = 0;
+    const int pb_c = wave & 3, pb_x0 = (wave >> 2) * CPL * U.wsz + lane;
+    unsigned long long fl_acc = 0;
+    uint32_t *plb = (uint32_t *)(fig_lds + fig_u(E.off_plb));
+    // tiles of the placement range [-(L-1), G-1] and their deal over the waves: full rounds of nw tiles with all 32 reads,
+    // then the tiles left over split by reads over f waves each
+    const int Wn = G + U.L - 1;
+    const int nT = (Wn + 63) >> 6;
+    const int nfull = nT / nw, mleft = nT - nfull * nw;
+    int fsplit = 1;
+    if (mleft > 0) { while (fsplit * 2 * mleft <= nw && fsplit < 8) fsplit *= 2; }
+    const int nsl = FIG_SH_C / fsplit;                         // reads per wave in the split round
+    const bool has_left = mleft > 0 && wave < mleft * fsplit;
+    const int tile_left = nfull * nw + wave / fsplit, s0_left = (wave % fsplit) * nsl;
+    FIG_SYNC();                                                // placeReads zeroed countsGap already (:3050-3056)
+    FIG_T0(E);
+    for (int c0 = 0; c0 < nU; c0 += FIG_SH_C) {
+        // ---- insert-size windows and packed-read offsets of the chunk's reads
+        if (tid < 64) {
+            const int r = c0 + tid;
+            int lo = 0, hi = -1, tis0 = 0, dir = 1; bool irr = false;
+            int len = 0, aux = 0; long long woff = 0;
+            if (tid < FIG_SH_C && r < nU) {
+                len = U.u_len[ub + r]; aux = U.u_aux[ub + r]; woff = U.u_woff[ub + r];
+                const FigWin w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
+                lo = w.lo; hi = w.hi; tis0 = w.tis0; dir = w.dir;
+                irr = ((aux >> 1) & 1) != 0 || len != U.L;
+            }
+            if (tid < FIG_SH_C) { S.sh_lo[tid] = lo; S.sh_hi[tid] = hi; S.sh_tis0[tid] = tis0; S.sh_dir[tid] = dir; S.sh_len[tid] = len; S.sh_aux[tid] = aux; S.sh_woff[tid] = woff; }
+            const unsigned long long im = fig_ballot(irr);
+            if (tid == 0) S.sh_irr = (unsigned)(im & 0xffffffffULL);
+        }
+        FIG_SYNC();
+        // position lists of the chunk's first row group: fetched now, parked in plb when the group starts (wave t: row t)
+        uint32_t plv_next = 0;
+        if (wave < NR && c0 + wave < nU) {
+            const int len = fig_u(S.sh_len[wave]);
+            const int ndw = 2 + ((len + 3) >> 2) + 4;
+            if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+        }
+        FIG_TICK(E, 34);
+        // ---- phase A: lanes = placements, the raw products of all reads of the chunk -> prow
+        const fig_cu32p stc = stream0 + (long long)(c0 / FIG_SH_C) * U.L * (FIG_SH_C / 2);
+        for (int k = 0; k < nfull; k++) {
+            const int ob = -(U.L - 1) + 64 * (k * nw + wave), o = ob + lane;
+            const bool vo = o <= G - 1;
+            fig_sh_unit<32>(0, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+        }
+        if (has_left) {
+            const int ob = -(U.L - 1) + 64 * tile_left, o = ob + lane;
+            const bool vo = o <= G - 1;
+            if (fsplit == 1) fig_sh_unit<32>(0, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+            else if (fsplit == 2) fig_sh_unit<16>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+            else if (fsplit == 4) fig_sh_unit<8>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+            else fig_sh_unit<4>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+        }
+        FIG_TICK(E, 35);
+        FIG_SYNC();                                            // every wave's products are in prow
+        // ---- phase B: four reads at a time through the LDS weight rows.  Thread tid takes placements tid, tid + nt, ... of
+        // every row; the products of the next group are fetched while this group's column pass runs.
+        double pn[NR][KP];
+#pragma unroll
+        for (int t = 0; t < NR; t++)
+#pragma unroll
+            for (int k = 0; k < KP; k++) { const int i = tid + k * U.nt; pn[t][k] = (i < Wn && c0 + t < nU) ? prow[(long long)t * pst + i] : 0.0; }
+        for (int q0 = 0; q0 < FIG_SH_C && c0 + q0 < nU; q0 += NR) {
+            const unsigned irr = (unsigned)fig_u((int)S.sh_irr);
+            // the group's scalars, all four rows at once (lane t of every wave reads row t's, v_readlane hands them round)
+            int g_lo = 0, g_hi = -1, g_len = 0;
+            if (lane < NR && c0 + q0 + lane < nU) { g_lo = S.sh_lo[q0 + lane]; g_hi = S.sh_hi[q0 + lane]; g_len = S.sh_len[q0 + lane]; }
+            if (wave < NR) {
+                plb[wave * 64 + lane] = plv_next;              // fetched while the previous group ran
+                plv_next = 0;
+                const int sn = q0 + NR + wave;                 // the same row of the next group of this chunk
+                if (sn < FIG_SH_C && c0 + sn < nU) {
+                    const int len = fig_u(S.sh_len[sn]);
+                    const int ndw = 2 + ((len + 3) >> 2) + 4;
+                    if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+                }
+            }
+            if (tid < NR) { S.tm_lo[tid] = g_lo; S.tm_hi[tid] = g_hi; S.tm_len[tid] = g_len; }
+            double pc[NR][KP];
+#pragma unroll
+            for (int t = 0; t < NR; t++)
+#pragma unroll
+                for (int k = 0; k < KP; k++) pc[t][k] = pn[t][k];
+#pragma unroll
+            for (int t = 0; t < NR; t++) {
+                const int s = q0 + t, r = c0 + s;
+                if (r >= nU) continue;
+                const int lo = __builtin_amdgcn_readlane(g_lo, t), hi = __builtin_amdgcn_readlane(g_hi, t);
+                double *wrow = W + (long long)t * Wcap + (U.L - 1);
+                const bool isirr = (irr >> s) & 1u;
+                if (hi < lo) continue;
+                if (!isirr) {
+                    // weights of this read's placements: w = exp(0.5 log10 p) inside the read's window, 0 outside (:3591-3601);
+                    // the wave's maximal product (a non-negative double orders like its bit pattern) and one offset that
+                    // reaches it go to wv_v / wv_o
+                    double pr = 0.0; int po = FIG_NOPOS;
+#pragma unroll
+                    for (int k = 0; k < KP; k++) {
+                        const int i = tid + k * U.nt, o = i - (U.L - 1);
+                        if (k * U.nt + wave * 64 < Wn) {        // (wave-uniform: a wave without placements in this pass skips it)
+                            const bool in = i < Wn && o >= lo && o <= hi;
+                            const double tl = fig_log10(pc[t][k]);
+                            const double wv = fig_exp(0.5 * tl);
+                            if (i < Wn) wrow[o] = in ? wv : 0.0;
+                            if (in) {
+                                fl_acc += 4ULL * (unsigned long long)U.L + (unsigned long long)fig_ovl(o, U.L, G);
+                                if (pc[t][k] > pr) { pr = pc[t][k]; po = o; }
+                            }
+                        }
+                    }
+                    long long bits; memcpy(&bits, &pr, 8);
+                    const unsigned hi32 = (unsigned)((unsigned long long)bits >> 32), lo32 = (unsigned)((unsigned long long)bits & 0xffffffffULL);
+                    const unsigned mh = fig_wave_max_u32(hi32);
+                    const unsigned long long ah = fig_ballot(hi32 == mh);
+                    // (nearly always one lane holds the maximal high word: its low word is the maximum's)
+                    const unsigned ml = (ah & (ah - 1)) == 0ULL ? (unsigned)fig_lane_read_i32((int)lo32, fig_ctz64(ah)) : fig_wave_max_u32(hi32 == mh ? lo32 : 0u);
+                    const unsigned long long am = fig_ballot(po != FIG_NOPOS && hi32 == mh && lo32 == ml);
+                    const bool any = (mh | ml) != 0u && am != 0ULL;            // a product of 0 is no placement: log10 = -inf never beats -DBL_MAX
+                    const int ao = any ? fig_lane_read_i32(po, fig_ctz64(am)) : FIG_NOPOS;
+                    if (lane == 0) {
+                        const unsigned long long mb = ((unsigned long long)mh << 32) | ml;
+                        double mv; memcpy(&mv, &mb, 8);
+                        S.wv_v[t * 8 + wave] = any ? mv : 0.0; S.wv_o[t * 8 + wave] = ao;
+                    }
+                } else {
+                    // generic chain (N bases / short read): all lanes over the read's window, zero outside it
+                    FigReadS rs; rs.len = fig_u(S.sh_len[s]); rs.rev = fig_u(S.sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = fig_u64(S.sh_woff[s]);
+                    fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
+                    const int nw2 = (rs.len + 15) >> 4;
+                    fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
+                    const double *Q4 = fig_q4_ptr<LDS>(E);
+                    const int tis0 = fig_u(S.sh_tis0[s]), dir = fig_u(S.sh_dir[s]);
+                    for (int i = -(U.L - 1) + tid; i < G; i += U.nt) if (i < lo || i > hi) wrow[i] = 0.0;
+                    FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+                    unsigned long long nplace = 0, nadd = 0;
+                    for (int o = lo + tid; o <= hi; o += U.nt) {
+                        const double pr = fig_hot_chain_e<LDS>(PQ, Q4, U.ncolE, pk, nw2, kt, rs.len, 0, false, o + U.xoff, U.insd[tis0 + dir * o]);
+                        const double tl = fig_log10(pr);
+                        if (tl > best.v) { best.v = tl; best.o = o; }
+                        wrow[o] = fig_exp(0.5 * tl);
+                        nplace++; nadd += fig_ovl(o, rs.len, G);
+                    }
+                    fl_acc += 4ULL * nplace * (unsigned long long)rs.len + nadd;
+                    const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
+                    const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
+                    const int ao = am ? fig_lane_read_i32(best.o, fig_ctz64(am)) : FIG_NOPOS;
+                    if (lane == 0) { S.wv_v[t * 8 + wave] = bv; S.wv_o[t * 8 + wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; }
+                }
+            }
+            FIG_TICK(E, 36);
+            FIG_SYNC();
+            FIG_TICK(E, 37);
+            // the next group's products (their latency hides behind this group's column pass)
+            if (q0 + NR < FIG_SH_C && c0 + q0 + NR < nU) {
+#pragma unroll
+                for (int t = 0; t < NR; t++)
+#pragma unroll
+                    for (int k = 0; k < KP; k++) { const int i = tid + k * U.nt; pn[t][k] = (i < Wn && c0 + q0 + NR + t < nU) ? prow[(long long)(q0 + NR + t) * pst + i] : 0.0; }
+            }
+            // ---- per-read bookkeeping (:3680-3688): regular reads hold products in wv_v (maxlv = log10 of the maximum: the
+            // same value the placement's own log10 gave), reads of the generic chain hold log10 values
+            if (tid >= 64 && tid < 64 + NR) {
+                const int t = tid - 64, s = q0 + t;
+                if (c0 + s < nU) {
+                    const bool isirr = (irr >> s) & 1u;
+                    FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
+                    if (S.sh_hi[s] >= S.sh_lo[s]) for (int k = 0; k < nw; k++) { FigBest y; y.v = S.wv_v[t * 8 + k]; y.o = S.wv_o[t * 8 + k]; b = fig_best_merge(b, y); }
+                    if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + s] = isirr ? b.v : fig_log10(b.v);
+                    else { E.scr.maxlv[c0 + s] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
+                    E.scr.hint_e[c0 + s] = b.o;
+                }
+            }
+            // ---- column pass over the group's rows (as fig_hot_estep: base-owning waves, register accumulators)
+            for (int t = 0; t < NR && c0 + q0 + t < nU; t++) {
+                if (U.nw == 8) { if ((t + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
+                const int lo = fig_u(S.tm_lo[t]), hi = fig_u(S.tm_hi[t]);
+                if (hi < lo) continue;
+                const double *wrow = W + (long long)t * Wcap + (U.L - 1);
+                const uint32_t plv = plb[t * 64 + lane];
+                const uint32_t cw0 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 0), cw1 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 1);
+                const int nA = (int)(cw0 & 255), nC = (int)((cw0 >> 8) & 255), nG = (int)((cw0 >> 16) & 255), nT_ = (int)(cw0 >> 24);
+                const int n4 = (int)(cw1 & 255);
+                const int dC = 2 + ((nA + 3) >> 2), dG = dC + ((nC + 3) >> 2), dT = dG + ((nG + 3) >> 2), d4 = dT + ((nT_ + 3) >> 2);
+                const int n = pb_c == 0 ? nA : pb_c == 1 ? nC : pb_c == 2 ? nG : nT_;
+                const int d0 = pb_c == 0 ? 2 : pb_c == 1 ? dC : pb_c == 2 ? dG : dT;
+                const double *wl = wrow + pb_x0;
+                int k4 = 0;
+                for (; k4 + 1 <= (n >> 2); k4++) {
+                    const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
+                    const double *p0 = wl - (int)(s4 & 255), *p1 = wl - (int)((s4 >> 8) & 255), *p2 = wl - (int)((s4 >> 16) & 255), *p3 = wl - (int)(s4 >> 24);
+                    if (CPL <= 4) {
+                        double w0[CPL], w1[CPL], w2[CPL], w3[CPL];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p0 + i * 64); w1[i] = FIG_LDV(p1 + i * 64); w2[i] = FIG_LDV(p2 + i * 64); w3[i] = FIG_LDV(p3 + i * 64); }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w0[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w1[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w2[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w3[i];
+                    } else {
+                        double w0[CPL], w1[CPL];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p0 + i * 64); w1[i] = FIG_LDV(p1 + i * 64); }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w0[i];
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p2 + i * 64); acc[i] += w1[i]; }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) { w1[i] = FIG_LDV(p3 + i * 64); acc[i] += w0[i]; }
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w1[i];
+                    }
+                }
+                if (n & 3) {
+                    uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
+                    for (int qq = 0; qq < (n & 3); qq++, s4 >>= 8) {
+                        const double *p0 = wl - (int)(s4 & 255);
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += FIG_LDV(p0 + i * 64);
+                    }
+                }
+                if (n4 > 0) {
+                    for (int x = tid; x < G; x += U.nt) {
+                        double a = E.scr.cnt[4 * cg + x];
+                        for (int k = 0; k < n4; k++) {
+                            const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d4 + (k >> 2));
+                            a += wrow[x - (int)((s4 >> ((k & 3) * 8)) & 255)];
+                        }
+                        E.scr.cnt[4 * cg + x] = a;
+                    }
+                }
+            }
+            if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
+            FIG_TICK(E, 38);
+            FIG_SYNC();
+            FIG_TICK(E, 39);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < CPL; i++) {
+        const int x = pb_x0 + i * U.wsz;
+        if (x < G) E.scr.cnt[pb_c * cg + x] = acc[i];
+    }
+    E.flops += fl_acc;
+    FIG_SYNC();
+}
+
+// Can this E-step take the shared-factor form?  (LDS table, not tiled, >= 4 weight rows, the gap not clipped by the contig
+// start, at most two placements per thread and row in phase B, at most 8 column tiles per wave.)
+FIG_D bool fig_sh_applies(const FigEng &E, int cpl) {
+    if (!E.sh_on || E.tiles > 0 || !E.pq_lds || E.nteams < 4 || cpl > 8 || cpl < 1) return false;
+    if (!E.B->ustream || E.M->L < 32) return false;
+    const FigState &S = *E.S;
+    if (S.left < E.xoff) return false;
+    const int Wn = S.G + E.M->L - 1;
+    return Wn <= 2 * E.nt && (E.nw == 4 || E.nw == 8) && (long long)FIG_SH_C * E.Wcap <= (long long)E.B->capW;
+}
+
+#endif  // !FIG_EMU
+#endif

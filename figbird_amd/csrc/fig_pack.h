@@ -76,7 +76,7 @@ struct FigPacked {
     std::vector<int64_t> u_woff, p_woff, p_qoff, str_off;
     std::vector<FigLaunchClass> classes;
     int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0, capE = 0;
-    int64_t str_total = 0, n_gaps = 0, persist_total = 0;
+    int64_t str_total = 0, n_gaps = 0, persist_total = 0, stream_total = 0;   // stream_total: dwords of the operand-select stream
     int nslots = 64;                  // speculative candidate slots per gap (fig_engine_sched.h)
     int64_t packed_bytes() const {
         return (int64_t)(packed.size() * 4 + flank.size() + gaps.size() * sizeof(FigDevGap) + qual.size() +
@@ -175,6 +175,14 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         if (d.fillflag == -1) cost[g] = 1;
     }
     K.str_total = str_total; K.str_off[ng] = str_total;
+    {   // operand-select stream of the shared-factor E-step: per gap ceil(nU/32) chunks x L steps x 16 dwords (32 16-bit entries), built on the device
+        int64_t so = 0;
+        for (int64_t g = 0; g < ng; g++) {
+            K.gaps[g].streamOff = so;
+            so += (int64_t)((K.gaps[g].nU + FIG_SH_C - 1) / FIG_SH_C) * m->max_read_length * (FIG_SH_C / 2);
+        }
+        K.stream_total = so + FIG_SH_C;        // + one padded step: the chain prefetches the row after the last one
+    }
     K.capG = (K.capG + 7) & ~7;
     {   // which gaps find the reference's process-level overlap_threshold already at 5 (fig_gaprules.h): given by the caller
         // (gap_ot_preset: it knows which worker process of the reference a gap would run in, and which gaps of that process
@@ -269,7 +277,8 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             K.classes.push_back(c);
         }
         K.capE = std::max(K.capE, c.ncolE);
-        K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
+        K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);
+        if (m->unmapped_flag && c.lds_tab && !c.tiles && c.nteams >= 4) K.capW = std::max(K.capW, FIG_SH_C * c.Wcap + 1024);   // product rows of the shared-factor E-step (fig_engine_shared.h)   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
     }
     return FIG_OK;
 }

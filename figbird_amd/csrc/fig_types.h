@@ -14,6 +14,8 @@
 #define FIG_MAX_GAP 100000           // MAX_GAP, Figbird.cpp:30
 #define FIG_FLANK 208                // flank window kept per side: >= max(read length, side_limit=30)
 #define FIG_DBL_MAX 1.7976931348623157e308
+#define FIG_SH_C 32                  // reads per chunk of the shared-factor E-step (fig_engine_shared.h)
+#define FIG_SH_ONE 16                // operand-select register offset of the constant 1.0 (slots without a regular read)
 #define FIG_MLE_FB 208               // doubles of the per-wave factor buffer of the MLE pass (>= FIG_MAX_READLEN)
 // LDS-tiled class: doubles of LDS the MLE pass needs to run its LDS form over all ncolE columns: C[5][ncolE], one 16-byte
 // packed-consensus record per column, the per-wave factor buffers, the packed consensus words (kc, kn) and slack
@@ -45,6 +47,7 @@ struct FigDevGap {
     int32_t gapNo; int32_t cls;
     int64_t persistOff;              // this gap's persistent slab (candidate-parallel mode)
     int32_t capGg, rangeCap, nslots, pad;
+    int64_t streamOff;               // first dword of this gap's operand-select stream (FigDevBatch::ustream)
 };
 
 struct FigDevReads {                 // batch-wide SoA, one entry per read
@@ -63,6 +66,7 @@ struct FigDevBatch {
     const int32_t *order;            // gap indices, most expensive first
     FigDevReads u, p;
     const uint32_t *packed;          // all packed reads
+    const uint32_t *ustream;         // operand-select stream of the unmapped reads: per gap [chunk of 32 reads][step j < L][32] 16-bit entries (fig_engine_shared.h)
     const uint8_t *qual;             // partial qualities
     const uint8_t *flank;            // per-gap flank codes
     // outputs
