@@ -391,20 +391,20 @@ def write_case(case: Case, root: str) -> dict:
 
 
 def figbird_argv(case: Case, paths: dict, thread_id: int = 0, n_gaps_for_thread: Optional[int] = None,
-                 gapthresh: int = 400) -> List[str]:
+                 gapthresh: int = 400, set_inputmean: int = 0) -> List[str]:
     """The 16 positional args of Figbird.cpp main (Figbird.cpp:6957-6973)."""
     n = len(case.gaps) if n_gaps_for_thread is None else n_gaps_for_thread
     return [paths["scf"], str(case.max_distance), str(case.read_len), str(case.script_itr),
             str(case.partial_flag), str(case.unmapped_flag), str(thread_id), str(n),
             paths["myout"], paths["tmp"], paths["gaps"], str(case.neg_overlap),
-            str(case.partial_len), str(gapthresh), "0", str(int(case.insert_mean))]
+            str(case.partial_len), str(gapthresh), str(set_inputmean), str(int(case.insert_mean))]
 
 
-def fillgaps_argv(case: Case, paths: dict, n_threads: int = 1) -> List[str]:
+def fillgaps_argv(case: Case, paths: dict, n_threads: int = 1, set_inputmean: int = 0) -> List[str]:
     """The 15 positional args of FillGaps.cpp main (FillGaps.cpp:419-433)."""
     return [paths["scf"], str(case.max_distance), str(case.read_len), str(case.script_itr),
             str(case.partial_flag), str(case.unmapped_flag), str(n_threads), paths["myout"],
-            paths["tmp"], paths["gaps"], str(case.neg_overlap), str(case.partial_len), "10", "0",
+            paths["tmp"], paths["gaps"], str(case.neg_overlap), str(case.partial_len), "10", str(set_inputmean),
             str(int(case.insert_mean))]
 
 

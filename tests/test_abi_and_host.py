@@ -72,6 +72,23 @@ def test_host_model_equals_oracle_model(tmp_path):
     assert abs(m.T.reshape(5, 5).sum(axis=1) - 1).max() < 1e-12
 
 
+def test_set_inputmean_changes_the_model_as_in_the_reference(tmp_path):
+    """set_inputmean = 1 (Figbird.cpp:6971-6973, used at :913): pairs on a contig no longer than the insert size stay out of the
+    insert-size histogram.  The `inputmean` fixture (reference outputs made with the flag on) has such a contig: the host
+    model equals the oracle's with the flag on, and differs from the model built with the flag off."""
+    root = util.extract_golden("inputmean", str(tmp_path))
+    a = util.meta(root)["fillgaps_argv"]
+    assert a[13] == "1"
+    tr = str(tmp_path / "t.trace")
+    assert util.run_oracle_fillgaps(root, trace=tr).returncode == 0
+    _, om = util.parse_trace(tr)
+    kw = dict(partial_flag=0, unmapped_flag=1, script_itr=1, max_distance=int(a[1]), read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
+    on = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"), setinputmean=1, isz=int(a[14]), **kw)
+    off = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"), setinputmean=0, isz=int(a[14]), **kw)
+    assert (on.cutoff, on.Tmin, on.Tmax) == om[:3] and on.stats == om[3:]
+    assert on.stats != off.stats and (on.Tmin, on.Tmax) != (off.Tmin, off.Tmax)
+
+
 def test_case_to_batch_applies_parse_unmapped_orientation():
     c = synth.make_case("t", 5, "unmapped", [(3000, 30)], coverage=6, n_model_pairs=50)
     b = synth.case_to_batch(c)

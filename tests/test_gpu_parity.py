@@ -17,7 +17,7 @@ def _loaded_native():
     return "libfighip.so" in maps
 
 
-@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+@pytest.mark.parametrize("name", util.GOLDEN_CASES + util.BENCH_GOLDENS)
 def test_figfill_on_gpu_matches_reference_outputs(name, tmp_path):
     """figfill (shipped host + libfighip.so) on the reference's own golden outputs: byte-identical files."""
     root = util.extract_golden(name, str(tmp_path))
@@ -70,6 +70,59 @@ def test_gpu_fuzz_against_oracle(seed, tmp_path):
     from tools.fuzz_ref import mk
     from tools.compare_emu import run_one
     assert run_one(mk(seed), str(tmp_path), exe=util.FIGFILL, verbose=False)
+
+
+@pytest.mark.parametrize("name", util.BENCH_GOLDENS)
+def test_bench_regime_candidates_and_planes_match_the_pinned_oracle(name, tmp_path, monkeypatch):
+    """The regime bench.py's step lives in (L = 150, insert N(3500, 350), 600-3000 reads per gap, 270-320 candidate lengths x
+    8-16 EM iterations through the speculative scheduler and its five early-stop rules, Figbird.cpp:6298-6482), against
+    fixtures made ONCE with the reference's own binaries (tools/make_bench_golden.py): through the C ABI, every candidate
+    record (gapEstimate, EM iterations, valid_count exact; likelihood <= 1e-6) and, for a spread of candidates, planes (i)
+    countsGap and (ii) the per-read E-step maxima <= 1e-6 against the trace of the oracle whose text outputs equalled the
+    reference's bytes on these very inputs.  bench_c1100 / bench_t1800 cover the one-weight-row and the LDS-tiled class."""
+    import json
+    from tools import make_bench_golden as mbg
+    root = util.extract_golden(name, str(tmp_path))
+    ref = json.load(open(os.path.join(root, "ref", "cands.json")))
+    planes = np.load(os.path.join(root, "ref", "planes.npz"))
+    batch, mc, spec = mbg.make(name)
+    a = util.meta(root)["fillgaps_argv"]
+    model = api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
+                                 partial_flag=int(a[4]), unmapped_flag=int(a[5]), script_itr=int(a[3]), max_distance=int(a[1]),
+                                 read_length=int(a[2]), neg_overlap=int(a[10]), partial_len=int(a[11]))
+    cols = max(int(c[0]) for c in ref["cands"]) + 1
+    nreads = int(batch.u_read_off[1])
+    eng = api.Engine(0)
+    assert _loaded_native()
+    eng.set_model(model)
+    res = eng.fill(batch, debug_cand=512, plane_cols=cols, plane_reads=nreads)
+    st = eng.stats()
+    eng.close()
+    exp = [ln.split("\t") for ln in util.read(os.path.join(root, "ref", "gapout.txt")).splitlines()]
+    assert [int(e[4]) for e in exp] == list(res.filled_len)
+    assert [e[5] if len(e) > 5 else "" for e in exp] == res.strings
+    got = res.cand[0]
+    assert len(got) == len(ref["cands"]), "candidate count"
+    for (G1, it1, likhex, v1), (G2, it2, v2, lik2) in zip(ref["cands"], got):
+        lik1 = float.fromhex(likhex)
+        assert (G1, it1, v1) == (G2, it2, v2), f"G={G1}"
+        if np.isfinite(lik1):
+            assert abs(lik1 - lik2) <= 1e-6 * max(1.0, abs(lik1)), f"G={G1}: {lik1} vs {lik2}"
+        else:
+            assert lik1 == lik2 or (np.isnan(lik1) and np.isnan(lik2))
+    from test_planes import _close
+    index = {c[0]: k for k, c in enumerate(got)}
+    assert len(ref["plane_cands"]) >= 1
+    for G in ref["plane_cands"]:
+        k = index[G]
+        cnt, rmax = planes[f"counts_{G}"], planes[f"rmax_{G}"]
+        ok, at = _close(res.counts[0, k, :G, :].reshape(-1), cnt.reshape(-1), 1e-6)
+        assert ok, f"G={G}: countsGap column {at // 5} base {at % 5}: {res.counts[0, k, at // 5, at % 5]!r} vs {cnt.reshape(-1)[at]!r}"
+        ok, at = _close(res.read_maxlv[0, k, :len(rmax)], rmax, 1e-6)
+        assert ok, f"G={G}: read {at}: {res.read_maxlv[0, k, at]!r} vs {rmax[at]!r}"
+    if ref.get("stats"):          # the oracle's placeReads calls and algorithmic flops on this gap = the device's useful-work counters
+        assert int(ref["stats"][0]) == int(st["place_calls"])
+        assert abs(float(ref["stats"][1]) - st["alg_flops"]) <= 1e-9 * float(ref["stats"][1])
 
 
 def _bench_engine(spec, seed=7):

@@ -252,3 +252,86 @@ def test_bench_starts_its_own_ranks(tmp_path):
     assert len(line) == 1, r.stdout
     d = json.loads(line[0])
     assert d["n_gpus"] == 2 and d["n_gaps"] == 48 and len(d["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and d["value"] > 0
+
+
+def _cfg4_worker(rank, world, port, workdir, q):
+    """One rank of the config-4 rehearsal: same seeded gap set on every rank, LPT shard, fill through the C ABI on the box's
+    one GPU, gloo all-gather of the packed results; rank 0 checks them."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    sys.path.insert(0, util.ROOT)
+    import subprocess
+    import torch.distributed as dist
+    from figbird_amd import api, synth
+    dist.init_process_group("gloo")
+    try:
+        n_gaps, L = 2048, 100
+        spec = synth.BenchSpec(mode="unmapped", read_len=L, insert_mean=2500.0, insert_sd=250.0, reads_per_gap_mean=48.0, frag_len=L)
+        mc = synth.bench_model_case(7, spec)
+        mp = synth.write_case(mc, os.path.join(workdir, f"model_r{rank}"))
+        model = api.model_from_files(mp["scf"], mp["tmp"], mp["myout"], partial_flag=0, unmapped_flag=1, script_itr=1,
+                                     max_distance=spec.max_distance, read_length=L, neg_overlap=30, partial_len=mc.partial_len)
+        batch, truth = synth.make_bench_batch(4004, n_gaps, spec)
+        cost = fdist.estimate_cost(np.asarray(batch.gap_len), np.diff(batch.u_read_off), L, True, mc.partial_len)
+        shards = fdist.partition_lpt(cost, world)
+        mine = shards[rank]
+        eng = api.Engine(0)
+        eng.set_model(model)
+        res = eng.fill(synth.subset_batch(batch, mine))
+        eng.close()
+        fl, gt, ps = fdist.all_gather_packed(mine, res, n_gaps)
+        out = {"rank": rank, "n_mine": len(mine), "native": "libfighip.so" in open("/proc/self/maps").read()}
+        if rank == 0:
+            strings = ps.to_list()
+            called = wrong = 0
+            for s_, t in zip(strings, truth):
+                if len(s_) == len(t):
+                    a = np.frombuffer(s_.encode(), dtype=np.uint8)
+                    m = a != ord("N")
+                    called += int(m.sum()); wrong += int((a[m] != t[m]).sum())
+            out.update(called=called, wrong=wrong, n_strings=len(strings), filled=int(ps.filled_bases()))
+            # stratified oracle sample: the cheapest gap of each findFrac bracket (one of them from each rank's shard at least)
+            G = np.asarray(batch.gap_len); nr = np.diff(batch.u_read_off)
+            sample = []
+            for lo, hi in [(5, 31), (31, 134), (134, 401), (401, 800), (800, 2001)]:
+                ids = [g for g in range(n_gaps) if lo <= G[g] < hi]
+                sample.append(min(ids, key=lambda g: (int(nr[g]) * (int(G[g]) if G[g] <= 400 else 1), g)))
+            paths = synth.write_batch_subset(batch, sample, mc, os.path.join(workdir, "cpu"), spec)
+            args = [paths["scf"], str(spec.max_distance), str(L), "1", "0", "1", "1", paths["myout"], paths["tmp"], paths["gaps"],
+                    "30", str(mc.partial_len), "10", "0", str(int(spec.insert_mean))]
+            r = subprocess.run([util.ORACLE, "fillgaps"] + args, cwd=workdir, capture_output=True, text=True, timeout=900)
+            ok = r.returncode == 0
+            lines = open(paths["tmp"] + "gapout.txt").read().splitlines() if ok else []
+            for k, g in enumerate(paths["gap_order"]):
+                if ok and g in sample:
+                    f = lines[k].split("\t")
+                    ok = int(f[4]) == int(fl[g]) and (f[5] if len(f) > 5 else "") == strings[g]
+            out.update(oracle_identical=bool(ok), sample=[int(g) for g in sample], sample_owner=[int(g in set(mine)) for g in sample])
+        dist.barrier()
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_config4_shape_two_ranks_shard_fill_gather(tmp_path):
+    """BASELINE config 4's shape (chr14-like: thousands of gaps, 2x100-bp jump reads) through the multi-rank path: 2 048 gaps of
+    the GAGE mix dealt LPT on estimated cost to two ranks (the role of FillGaps.cpp:456-649), each rank fills its shard on the
+    device, one packed all-gather reassembles them; every called base equals the synthetic truth (to the error rate), and a
+    stratified sample (one gap per findFrac bracket) equals the oracle byte for byte."""
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_cfg4_worker, args=(r, 2, port, str(tmp_path), q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = {o["rank"]: o for o in (q.get(timeout=1500) for _ in ps)}
+    for p in ps:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert outs[0]["native"] and outs[1]["native"]
+    assert outs[0]["n_mine"] + outs[1]["n_mine"] == 2048 and min(outs[0]["n_mine"], outs[1]["n_mine"]) > 600
+    r0 = outs[0]
+    assert r0["n_strings"] == 2048 and r0["called"] > 100000 and r0["wrong"] <= 0.003 * r0["called"], r0
+    assert r0["oracle_identical"], r0
+    assert 0 < sum(r0["sample_owner"]) < len(r0["sample_owner"])          # the sample spans both ranks' shards

@@ -9,7 +9,7 @@ import pytest
 import util
 
 
-@pytest.mark.parametrize("name", util.GOLDEN_CASES)
+@pytest.mark.parametrize("name", util.GOLDEN_CASES + util.BENCH_GOLDENS_CPU)
 def test_oracle_matches_reference_figbird_main(name, tmp_path):
     root = util.extract_golden(name, str(tmp_path))
     r = util.run_oracle_figbird(root)

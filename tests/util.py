@@ -21,7 +21,13 @@ FIGFILL = pbuild.FIGFILL
 REF_FIGBIRD = os.path.join(fbuild.REFDIR, "Figbird.out")
 
 NON_FILL_GOLDENS = {"plumbing", "preprocess_boundary", "pipeline_e2e"}       # fixtures of the stages either side of the fill (tests/test_plumbing.py)
-GOLDEN_CASES = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz") and f[:-7] not in NON_FILL_GOLDENS) if os.path.isdir(GOLDEN) else []
+_ALL_FILL = sorted(f[:-7] for f in os.listdir(GOLDEN) if f.endswith(".tar.gz") and f[:-7] not in NON_FILL_GOLDENS) if os.path.isdir(GOLDEN) else []
+# bench_*: fixtures at bench.py's own regime (tools/make_bench_golden.py; L = 150, insert 3500, hundreds to thousands of reads per
+# gap).  A <= 400-bp gap of that shape costs the CPU oracle 10^3 s, so only the GPU tests run them all; the two one-candidate
+# fixtures are cheap enough for the CPU suite.
+BENCH_GOLDENS = [n for n in _ALL_FILL if n.startswith("bench_")]
+BENCH_GOLDENS_CPU = [n for n in BENCH_GOLDENS if n in ("bench_c1100",)]
+GOLDEN_CASES = [n for n in _ALL_FILL if not n.startswith("bench_")]
 FIGTOOL = pbuild.FIGTOOL
 
 

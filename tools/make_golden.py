@@ -38,8 +38,13 @@ CASES = {
     # draw files one after the other, and each process starts with its own overlap_threshold = 0 (Figbird.cpp:103, :6317)
     "threads3": dict(seed=977, mode="partial", gap_specs=[(1000, 30), (2000, 35), (3000, 24), (4000, 35), (5000, 28), (6000, 40), (7000, 33), (7900, 450)],
                      contig_len=9500, insert_mean=180, insert_sd=10, coverage=18, err=0.003, n_model_pairs=600),
+    # ---- round 3: set_inputmean = 1 (Figbird.cpp:6971-6973): pairs on a contig no longer than the library's insert size do not
+    # feed the insert-size histogram (:907-914).  The case carries a second, 400-bp scaffold with 260 model pairs of ~300 bp
+    # inserts: counted with the flag off (inputMean = 0), dropped with it on, which moves the model's mean / SD / thresholds.
+    "inputmean": dict(seed=103, mode="unmapped", gap_specs=[(3000, 30), (6000, 90)], coverage=12, err=0.005, n_model_pairs=700),
 }
 N_THREADS = {"threads3": 3}
+SET_INPUTMEAN = {"inputmean": 1}
 
 
 def _post_edge_no_reads(case):
@@ -102,7 +107,22 @@ def _post_threads3(case):
         g.partial = reads
 
 
-POST = {"threads3": _post_threads3, "edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
+def _post_inputmean(case):
+    rng = synth.np.random.default_rng(synth.np.random.PCG64(1031))
+    short = synth._rand_seq(rng, 400)
+    case.scaffolds.append(short); case.truth.append(short)
+    L = case.read_len
+    for k in range(260):
+        isz = int(round(rng.normal(300, 8)))
+        p0 = int(rng.integers(0, 400 - isz))
+        r1 = short[p0:p0 + L]; r2 = short[p0 + isz - L:p0 + isz]
+        q = f"s1_{k}"
+        case.myout.append("\t".join([q, "99", "1", str(p0 + 1), f"{L}M", str(isz), r1, "I" * L, f"MD:Z:{L}", "IH:i:1"]))
+        case.myout.append("\t".join([q, "147", "1", str(p0 + isz - L + 1), f"{L}M", str(-isz), r2, "I" * L, f"MD:Z:{L}", "IH:i:1"]))
+    case.n_pairs = len(case.myout) // 2
+
+
+POST = {"inputmean": _post_inputmean, "threads3": _post_threads3, "edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
 
 
 def make(name):
@@ -122,7 +142,8 @@ def build(name, kw=None, keep=None):
     synth.write_gaploads(p, list(range(len(case.gaps))))
     refdir = os.path.join(root, "ref")
     os.makedirs(refdir)
-    r = subprocess.run([os.path.join(REF, "Figbird.out")] + synth.figbird_argv(case, p), capture_output=True, text=True)
+    sim = SET_INPUTMEAN.get(name, 0)
+    r = subprocess.run([os.path.join(REF, "Figbird.out")] + synth.figbird_argv(case, p, set_inputmean=sim), capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
     for fn in ("gapout0.txt", "gaptofill0.txt", "draw0.txt"):
         shutil.move(p["tmp"] + fn, os.path.join(refdir, fn))
@@ -131,7 +152,7 @@ def build(name, kw=None, keep=None):
     cwd = os.path.join(base, "cwd"); os.makedirs(cwd)
     os.symlink("/root/reference/Figbird.cpp", os.path.join(cwd, "Figbird.cpp"))
     nthr = N_THREADS.get(name, 1)
-    r = subprocess.run([os.path.join(REF, "FillGaps.out")] + synth.fillgaps_argv(case, p, n_threads=nthr), capture_output=True, text=True, cwd=cwd)
+    r = subprocess.run([os.path.join(REF, "FillGaps.out")] + synth.fillgaps_argv(case, p, n_threads=nthr, set_inputmean=sim), capture_output=True, text=True, cwd=cwd)
     assert r.returncode == 0, r.stderr
     for fn in ("gapout.txt", "filledContigs.fa", "Ncount.txt", "draw.txt"):
         shutil.move(p["tmp"] + fn, os.path.join(refdir, fn))
@@ -139,8 +160,8 @@ def build(name, kw=None, keep=None):
         shutil.move(p["tmp"] + "gaploads.txt", os.path.join(refdir, "gaploads.txt"))      # FillGaps.cpp:313-334, as the reference left it
     else:
         os.remove(p["tmp"] + "gaploads.txt")
-    meta = {"name": name, "figbird_argv": ["scf.fa"] + synth.figbird_argv(case, p)[1:8] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.figbird_argv(case, p)[11:],
-            "fillgaps_argv": ["scf.fa"] + synth.fillgaps_argv(case, p, n_threads=nthr)[1:7] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.fillgaps_argv(case, p)[10:],
+    meta = {"name": name, "figbird_argv": ["scf.fa"] + synth.figbird_argv(case, p)[1:8] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.figbird_argv(case, p, set_inputmean=sim)[11:],
+            "fillgaps_argv": ["scf.fa"] + synth.fillgaps_argv(case, p, n_threads=nthr)[1:7] + ["tmp/myout.sam", "tmp/", "gaps/"] + synth.fillgaps_argv(case, p, set_inputmean=sim)[10:],
             "mode": case.mode, "n_gaps": len(case.gaps), "truth": [g.truth for g in case.gaps]}
     with open(os.path.join(root, "meta.json"), "w") as f:
         json.dump(meta, f)
