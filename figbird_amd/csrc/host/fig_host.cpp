@@ -828,6 +828,70 @@ bool write_scaffold(const RunArgs &a, const Scaffold &sc, const Batch &b, const 
 
 // ------------------------------------------------------------------ C wrappers (libfighost.so)
 // Used by the Python tests / bench to obtain the run-level model exactly as figfill builds it.
+namespace fighost {
+
+void make_shard(const Batch &B, const std::vector<int64_t> &ids, Batch &S) {
+    S = Batch();
+    S.u_read_off.push_back(0); S.p_read_off.push_back(0); S.u_seq_off.push_back(0); S.p_seq_off.push_back(0);
+    const size_t ng = B.gap_contig.size();
+    for (int64_t g : ids) {
+        S.gap_contig.push_back(B.gap_contig[g]); S.gap_start.push_back(B.gap_start[g]); S.gap_len.push_back(B.gap_len[g]);
+        for (int q = 0; q < 3; q++) S.gap_stat2.push_back(B.gap_stat2[g * 3 + q]);
+        S.gap_fillflag.push_back(B.gap_fillflag[g]);
+        S.gap_ot_preset.push_back(B.gap_ot_preset.size() == ng ? B.gap_ot_preset[g] : 0);
+        for (int64_t i = B.u_read_off[g]; i < B.u_read_off[g + 1]; i++) {
+            S.u_anchor_pos.push_back(B.u_anchor_pos[i]); S.u_is_reverse.push_back(B.u_is_reverse[i]);
+            S.u_seq.append(B.u_seq, (size_t)B.u_seq_off[i], (size_t)(B.u_seq_off[i + 1] - B.u_seq_off[i]));
+            S.u_seq_off.push_back((int64_t)S.u_seq.size());
+        }
+        S.u_read_off.push_back((int64_t)S.u_anchor_pos.size());
+        for (int64_t i = B.p_read_off[g]; i < B.p_read_off[g + 1]; i++) {
+            S.p_clipped_index.push_back(B.p_clipped_index[i]); S.p_match.push_back(B.p_match[i]); S.p_pos.push_back(B.p_pos[i]); S.p_ref_pos.push_back(B.p_ref_pos[i]);
+            S.p_seq.append(B.p_seq, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
+            S.p_qual.append(B.p_qual, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
+            S.p_seq_off.push_back((int64_t)S.p_seq.size());
+        }
+        S.p_read_off.push_back((int64_t)S.p_clipped_index.size());
+    }
+}
+
+std::vector<double> estimate_cost(const Batch &b, const RunArgs &a, int L) {
+    const size_t ng = b.gap_len.size();
+    std::vector<double> c(ng, 1.0);
+    for (size_t g = 0; g < ng; g++) {
+        const double G = b.gap_len[g];
+        if (a.unmapped == 1) {
+            const double R = (double)(b.u_read_off[g + 1] - b.u_read_off[g]);
+            const double cand = G <= a.unm_limit / 3 ? 3.0 * a.partial_len - 0.3 * G : (G <= a.unm_limit ? 2.0 * G : 1.0);
+            const double its = G <= a.unm_limit / 3 ? 10.5 : (G <= a.unm_limit ? 8.7 : 2.0);      // placeReads calls per candidate (tools/cost_model_check.py)
+            const double W = std::min(G * (G <= a.unm_limit ? 1.5 : 1.0) + L, 2200.0);
+            c[g] = R * W * L * std::max(cand, 1.0) * its + 1.0;
+        } else {
+            const double R = (double)(b.p_read_off[g + 1] - b.p_read_off[g]);
+            const double cand = G <= a.partial_len ? 3.0 * a.partial_len : (G <= 2 * a.partial_len ? 5.0 * G : 1.0);
+            c[g] = R * (double)L * L * std::max(cand, 1.0) * 3.0 + 1.0;
+        }
+    }
+    return c;
+}
+
+std::vector<std::vector<int64_t>> partition_lpt(const std::vector<double> &cost, int world) {
+    std::vector<int64_t> order(cost.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int64_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return cost[x] > cost[y]; });
+    std::vector<double> load((size_t)world, 0.0);
+    std::vector<std::vector<int64_t>> bins((size_t)world);
+    for (int64_t g : order) {
+        size_t r = 0;
+        for (size_t k = 1; k < load.size(); k++) if (load[k] < load[r]) r = k;
+        bins[r].push_back(g); load[r] += cost[g];
+    }
+    for (auto &b : bins) std::sort(b.begin(), b.end());
+    return bins;
+}
+
+}  // namespace fighost
+
 extern "C" int fighost_build_model(const char *contig_file, const char *tmp_dir, const char *map_file, int partial_flag,
                                    int partial_len, int setinputmean, int isz, int max_read_cap, int insd_cap,
                                    double *e, double *ins, double *del, double *T25, double *insd, int *ints5, double *stats3) {
@@ -897,35 +961,26 @@ extern "C" int fighost_run_model(void *h, fig_model *out) { Run *r = (Run *)h; r
 // Sub-batch of the gaps `ids` (any order; kept in that order), owned by the handle until the next call.
 extern "C" int fighost_run_shard(void *h, const int64_t *ids, int64_t n, fig_gap_batch *out, int64_t *n_ureads, int64_t *n_preads) {
     Run *r = (Run *)h;
-    const fighost::Batch &B = r->B;
-    fighost::Batch &S = r->sub;
-    S = fighost::Batch();
-    S.u_read_off.push_back(0); S.p_read_off.push_back(0); S.u_seq_off.push_back(0); S.p_seq_off.push_back(0);
-    const int64_t ng = (int64_t)B.gap_contig.size();
-    for (int64_t k = 0; k < n; k++) {
-        const int64_t g = ids[k];
-        if (g < 0 || g >= ng) return -1;
-        S.gap_contig.push_back(B.gap_contig[g]); S.gap_start.push_back(B.gap_start[g]); S.gap_len.push_back(B.gap_len[g]);
-        for (int q = 0; q < 3; q++) S.gap_stat2.push_back(B.gap_stat2[g * 3 + q]);
-        S.gap_fillflag.push_back(B.gap_fillflag[g]);
-        S.gap_ot_preset.push_back(B.gap_ot_preset.size() == (size_t)ng ? B.gap_ot_preset[g] : 0);
-        for (int64_t i = B.u_read_off[g]; i < B.u_read_off[g + 1]; i++) {
-            S.u_anchor_pos.push_back(B.u_anchor_pos[i]); S.u_is_reverse.push_back(B.u_is_reverse[i]);
-            S.u_seq.append(B.u_seq, (size_t)B.u_seq_off[i], (size_t)(B.u_seq_off[i + 1] - B.u_seq_off[i]));
-            S.u_seq_off.push_back((int64_t)S.u_seq.size());
-        }
-        S.u_read_off.push_back((int64_t)S.u_anchor_pos.size());
-        for (int64_t i = B.p_read_off[g]; i < B.p_read_off[g + 1]; i++) {
-            S.p_clipped_index.push_back(B.p_clipped_index[i]); S.p_match.push_back(B.p_match[i]); S.p_pos.push_back(B.p_pos[i]); S.p_ref_pos.push_back(B.p_ref_pos[i]);
-            S.p_seq.append(B.p_seq, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
-            S.p_qual.append(B.p_qual, (size_t)B.p_seq_off[i], (size_t)(B.p_seq_off[i + 1] - B.p_seq_off[i]));
-            S.p_seq_off.push_back((int64_t)S.p_seq.size());
-        }
-        S.p_read_off.push_back((int64_t)S.p_clipped_index.size());
-    }
-    S.view(*out, r->sc);
-    *n_ureads = (int64_t)S.u_anchor_pos.size(); *n_preads = (int64_t)S.p_clipped_index.size();
+    const int64_t ng = (int64_t)r->B.gap_contig.size();
+    std::vector<int64_t> v(ids, ids + n);
+    for (int64_t g : v) if (g < 0 || g >= ng) return -1;
+    fighost::make_shard(r->B, v, r->sub);
+    r->sub.view(*out, r->sc);
+    *n_ureads = (int64_t)r->sub.u_anchor_pos.size(); *n_preads = (int64_t)r->sub.p_clipped_index.size();
     return 0;
+}
+
+// Which of `world` shards the C++ host (figfill with FIGFILL_DEVICES) puts every gap of the run `argv15` on: owner[g] = rank.
+// Returns the number of gaps, or -1.  (Lets the tests pin the C++ deal to the Python one of figfill_mp.)
+extern "C" int64_t fighost_partition(const char *const *argv15, int world, int32_t *owner) {
+    char err[256];
+    Run *r = (Run *)fighost_run_open(argv15, err, sizeof(err));
+    if (!r) return -1;
+    const int64_t ng = (int64_t)r->B.gap_contig.size();
+    std::vector<std::vector<int64_t>> sh = fighost::partition_lpt(fighost::estimate_cost(r->B, r->a, r->M.maxReadLength), world);
+    for (int k = 0; k < world; k++) for (int64_t g : sh[k]) owner[g] = k;
+    fighost_run_close(r);
+    return ng;
 }
 
 // gapout.txt, draw.txt, filledContigs.fa, Ncount.txt of the WHOLE gap set from arrays in global gap / read order

@@ -72,6 +72,14 @@ bool load_batch(const RunArgs &a, const Scaffold &sc, Batch &out, std::string &e
 bool load_batch_mem(const RunArgs &a, const Scaffold &sc, const std::vector<std::string> *gaps_text, const std::vector<std::string> *partial_text,
                     Batch &out, std::string &err);
 
+// ---- N GPUs from the C++ host (figfill with FIGFILL_DEVICES=0,1,...): the role of FillGaps.cpp:456-649 (deal the gaps) and
+// :668-679 (start the workers).  Estimated cost of every gap (R * W * L * candidates * placeReads calls, the candidate range of
+// findFrac, Figbird.cpp:6879-6906; same formula as figbird_amd/dist.py), a longest-processing-time-first deal into `world`
+// shards (ascending gap ids inside a shard), and a shard of a batch as a batch of its own (gap_ot_preset travels with it).
+std::vector<double> estimate_cost(const Batch &b, const RunArgs &a, int max_read_length);
+std::vector<std::vector<int64_t>> partition_lpt(const std::vector<double> &cost, int world);
+void make_shard(const Batch &b, const std::vector<int64_t> &ids, Batch &out);
+
 struct Results {
     std::vector<int32_t> filled_len, gaptofill, draw_pos, draw_isz, draw_len;
     std::vector<int64_t> str_off;

@@ -12,6 +12,7 @@
 #include <string>
 #include <vector>
 #include <chrono>
+#include <thread>
 
 #include "fig_host.h"
 #include "fig_sam.h"
@@ -19,6 +20,82 @@
 using namespace fighost;
 
 static int fail(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); return 1; }
+
+// ---- N GPUs of one node from this process (FIGFILL_DEVICES=0,1,...; the reference starts its own workers too,
+// FillGaps.cpp:668-679): the gaps are dealt longest-processing-time-first on estimated cost (fig_host.h; the role of
+// FillGaps.cpp:456-649), one host thread per GPU creates its own fig_ctx (contexts are independent, include/figbird_hip.h)
+// and fills its shard through fig_fill_gaps with no exchange on the data path; the shard results meet in host memory in
+// global gap / read order, so the writers below see exactly what a single-GPU run hands them.
+struct ShardRun { std::vector<int64_t> ids; Batch sub; Results R; fig_stats st; int rc = 0; std::string err; };
+
+static void run_shard(int device, const fig_model *fm, const Scaffold *sc, ShardRun *S) {
+    memset(&S->st, 0, sizeof(S->st));
+    fig_gap_batch fb; S->sub.view(fb, *sc);
+    const int64_t ng = fb.n_gaps;
+    if (ng == 0) return;
+    fig_ctx *ctx = nullptr;
+    int rc = fig_ctx_create(device, &ctx);
+    if (rc) { S->rc = rc; S->err = std::string("fig_ctx_create(") + std::to_string(device) + "): " + fig_strerror(rc); return; }
+    rc = fig_ctx_set_model(ctx, fm);
+    if (rc) { fig_ctx_destroy(ctx); S->rc = rc; S->err = std::string("fig_ctx_set_model: ") + fig_strerror(rc); return; }
+    Results &R = S->R;
+    const int64_t cap = fig_results_capacity(fm, &fb);
+    R.filled_len.assign(ng, 0); R.gaptofill.assign(ng, 0); R.str_off.assign(ng + 1, 0); R.str.assign((size_t)std::max<int64_t>(cap, 1), 'N');
+    const int64_t nr = (int64_t)S->sub.u_anchor_pos.size() + (int64_t)S->sub.p_pos.size();
+    R.draw_pos.assign((size_t)std::max<int64_t>(nr, 1), INT32_MIN); R.draw_isz.assign((size_t)std::max<int64_t>(nr, 1), 0); R.draw_len.assign((size_t)std::max<int64_t>(ng * 2, 1), -1);
+    fig_gap_results fr; memset(&fr, 0, sizeof(fr));
+    fr.filled_len = R.filled_len.data(); fr.gaptofill = R.gaptofill.data(); fr.str_off = R.str_off.data();
+    fr.str = &R.str[0]; fr.str_capacity = (int64_t)R.str.size();
+    fr.draw_pos = R.draw_pos.data(); fr.draw_isz = R.draw_isz.data(); fr.draw_len = R.draw_len.data();
+    rc = fig_fill_gaps(ctx, &fb, &fr);
+    fig_get_stats(ctx, &S->st);
+    fig_ctx_destroy(ctx);
+    if (rc) { S->rc = rc; S->err = std::string("fig_fill_gaps on device ") + std::to_string(device) + ": " + fig_strerror(rc); }
+}
+
+// Fill B over `devices`; on success R holds the whole gap set in global order.  Returns 0 or 1 (message in err).
+static int fill_multi(const std::vector<int> &devices, const RunArgs &a, const Scaffold &sc, const Batch &B, const fig_model &fm, Results &R,
+                      fig_stats &st, std::string &err) {
+    const int world = (int)devices.size();
+    const int64_t ng = (int64_t)B.gap_contig.size();
+    std::vector<std::vector<int64_t>> shards = partition_lpt(estimate_cost(B, a, fm.max_read_length), world);
+    std::vector<ShardRun> runs((size_t)world);
+    for (int r = 0; r < world; r++) { runs[r].ids = shards[r]; make_shard(B, shards[r], runs[r].sub); }
+    if (getenv("FIGFILL_SERIAL")) {                      // test knob: one shard after the other (the CPU emulation library keeps global state)
+        for (int r = 0; r < world; r++) run_shard(devices[r], &fm, &sc, &runs[r]);
+    } else {
+        std::vector<std::thread> th;
+        for (int r = 0; r < world; r++) th.emplace_back(run_shard, devices[r], &fm, &sc, &runs[r]);
+        for (auto &t : th) t.join();
+    }
+    for (int r = 0; r < world; r++) if (runs[r].rc) { err = "figfill: " + runs[r].err; return 1; }
+    // ---- merge in global gap order (strings compacted as fig_fill_gaps leaves them) and global read order
+    const int64_t NU = (int64_t)B.u_anchor_pos.size(), NP = (int64_t)B.p_pos.size();
+    R.filled_len.assign(ng, 0); R.gaptofill.assign(ng, 0); R.str_off.assign(ng + 1, 0);
+    R.draw_pos.assign((size_t)std::max<int64_t>(NU + NP, 1), INT32_MIN); R.draw_isz.assign((size_t)std::max<int64_t>(NU + NP, 1), 0); R.draw_len.assign((size_t)std::max<int64_t>(ng * 2, 1), -1);
+    std::vector<int> owner((size_t)ng, -1); std::vector<int64_t> local((size_t)ng, 0);
+    for (int r = 0; r < world; r++) for (size_t k = 0; k < runs[r].ids.size(); k++) { owner[runs[r].ids[k]] = r; local[runs[r].ids[k]] = (int64_t)k; }
+    memset(&st, 0, sizeof(st));
+    for (int r = 0; r < world; r++) {
+        st.kernel_ms = std::max(st.kernel_ms, runs[r].st.kernel_ms); st.place_calls += runs[r].st.place_calls; st.alg_flops += runs[r].st.alg_flops;
+        st.n_launches += runs[r].st.n_launches;
+    }
+    R.str.clear();
+    for (int64_t g = 0; g < ng; g++) {
+        const ShardRun &S = runs[owner[g]]; const int64_t k = local[g];
+        R.filled_len[g] = S.R.filled_len[k]; R.gaptofill[g] = S.R.gaptofill[k];
+        R.str_off[g] = (int64_t)R.str.size();
+        R.str.append(S.R.str, (size_t)S.R.str_off[k], (size_t)(S.R.str_off[k + 1] - S.R.str_off[k]));
+        R.draw_len[2 * g] = S.R.draw_len[2 * k]; R.draw_len[2 * g + 1] = S.R.draw_len[2 * k + 1];
+        const int64_t nu = B.u_read_off[g + 1] - B.u_read_off[g], np = B.p_read_off[g + 1] - B.p_read_off[g];
+        const int64_t snu = (int64_t)S.sub.u_anchor_pos.size();
+        for (int64_t i = 0; i < nu; i++) { R.draw_pos[B.u_read_off[g] + i] = S.R.draw_pos[S.sub.u_read_off[k] + i]; R.draw_isz[B.u_read_off[g] + i] = S.R.draw_isz[S.sub.u_read_off[k] + i]; }
+        for (int64_t i = 0; i < np; i++) { R.draw_pos[NU + B.p_read_off[g] + i] = S.R.draw_pos[snu + S.sub.p_read_off[k] + i]; R.draw_isz[NU + B.p_read_off[g] + i] = S.R.draw_isz[snu + S.sub.p_read_off[k] + i]; }
+    }
+    R.str_off[ng] = (int64_t)R.str.size();
+    if (R.str.empty()) R.str.assign(1, 'N');
+    return 0;
+}
 
 int main(int argc, char **argv) {
     if (argc < 16) {
@@ -34,6 +111,11 @@ int main(int argc, char **argv) {
     a.unm_limit = 400;                                   // gapthresh, FillGaps.cpp:22
     const char *dev_env = getenv("FIGFILL_DEVICE");
     int device = dev_env ? atoi(dev_env) : 0;
+    std::vector<int> devices;                            // FIGFILL_DEVICES=0,1,...,7: one shard, host thread and fig_ctx per listed GPU
+    if (const char *dl = getenv("FIGFILL_DEVICES")) {
+        for (const char *q = dl; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e != ',' ) break; }
+        if (devices.empty()) return fail("figfill: FIGFILL_DEVICES must be a comma-separated list of GPU ordinals");
+    }
     auto t0 = std::chrono::steady_clock::now();
 
     std::string err;
@@ -67,6 +149,21 @@ int main(int argc, char **argv) {
 
     fig_model fm; M.fill(fm, a);
     fig_gap_batch fb; B.view(fb, sc);
+    if (devices.size() > 1) {
+        Results R; fig_stats st;
+        if (fill_multi(devices, a, sc, B, fm, R, st, err)) return fail(err);
+        if (!write_gapout(a, B, R, err)) return fail(err);
+        if (!write_draw(a, B, R, err)) return fail(err);
+        if (!write_gaploads(a, B, err)) return fail(err);
+        if (!write_scaffold(a, sc, B, R, err)) return fail(err);
+        double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        printf("Time taken = %g seconds (%zu GPUs; slowest shard's device kernels %.3f ms, %lld placeReads calls)\n", secs, devices.size(), st.kernel_ms, (long long)st.place_calls);
+        printf("======================================\n");
+        printf("Iteration %d ends successfully\n", a.script_itr);
+        printf("======================================\n");
+        return 0;
+    }
+    if (devices.size() == 1) device = devices[0];
     fig_ctx *ctx = nullptr;
     int rc = fig_ctx_create(device, &ctx);
     if (rc) return fail(std::string("figfill: fig_ctx_create: ") + fig_strerror(rc));

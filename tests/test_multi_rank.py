@@ -335,3 +335,67 @@ def test_config4_shape_two_ranks_shard_fill_gather(tmp_path):
     assert r0["n_strings"] == 2048 and r0["called"] > 100000 and r0["wrong"] <= 0.003 * r0["called"], r0
     assert r0["oracle_identical"], r0
     assert 0 < sum(r0["sample_owner"]) < len(r0["sample_owner"])          # the sample spans both ranks' shards
+
+
+def _figfill_devices(root, exe, devices, serial=False):
+    env = {"FIGFILL_DEVICES": devices}
+    if serial:
+        env["FIGFILL_SERIAL"] = "1"          # the one-lane emulation library is not re-entrant; libfighip.so's contexts are
+    return util.run([exe] + util.meta(root)["fillgaps_argv"], root, env)
+
+
+@pytest.mark.parametrize("name,devices", [("threads3", "0,0"), ("unmapped_mid_err", "0,0,0"), ("partial_brackets", "0,0")])
+def test_figfill_devices_from_the_cpp_host_emulation(name, devices, tmp_path):
+    """N GPUs from the C++ host (FIGFILL_DEVICES, figfill_main.cpp: fill_multi): LPT shards in C++, one fig_ctx and host thread
+    per listed device, results merged in host memory -- here on the one-lane emulation library (every "device" is ordinal 0),
+    byte-identical to the reference's four files (and gaploads.txt for `threads3`, whose per-process overlap_threshold presets
+    travel with the shards)."""
+    root = util.extract_golden(name, str(tmp_path))
+    r = _figfill_devices(root, util.EMU, devices, serial=True)
+    assert r.returncode == 0, r.stderr
+    assert f"{len(devices.split(','))} GPUs" in r.stdout
+    for fn in util.ref_files(root):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
+def test_cpp_partition_matches_the_python_partition(tmp_path):
+    """fighost::estimate_cost / partition_lpt (C++) deal the gaps exactly as figbird_amd/dist.py does: figfill with
+    FIGFILL_DEVICES and figfill_mp put the same gaps on the same rank."""
+    import ctypes as C
+    from figbird_amd import api
+    root = util.extract_golden("threads3", str(tmp_path))
+    h = api.load_host_library()
+    h.fighost_partition.argtypes = [C.POINTER(C.c_char_p), C.c_int, api.c_i32_p]
+    h.fighost_partition.restype = C.c_int64
+    argv = util.meta(root)["fillgaps_argv"]
+    owner = np.full(64, -1, dtype=np.int32)
+    cwd = os.getcwd(); os.chdir(root)
+    try:
+        n = h.fighost_partition((C.c_char_p * 15)(*[a.encode() for a in argv]), 3, api._p(owner, api.c_i32_p))
+        assert n == util.meta(root)["n_gaps"]
+        hh = h.fighost_run_open((C.c_char_p * 15)(*[a.encode() for a in argv]), C.create_string_buffer(256), 256)
+        glen = np.zeros(n, dtype=np.int32); nu = np.zeros(n, dtype=np.int64); npp = np.zeros(n, dtype=np.int64)
+        h.fighost_run_sizes(hh, api._p(glen, api.c_i32_p), api._p(nu, api.c_i64_p), api._p(npp, api.c_i64_p))
+        par = np.zeros(6, dtype=np.int32); h.fighost_run_params(hh, api._p(par, api.c_i32_p))
+        h.fighost_run_close(hh)
+    finally:
+        os.chdir(cwd)
+    cost = fdist.estimate_cost(glen, npp if not par[2] else nu, int(par[0]), bool(par[2]), int(par[1]), int(par[3]))
+    py = fdist.partition_lpt(cost, 3)
+    assert [sorted(int(g) for g in range(n) if owner[g] == r) for r in range(3)] == py
+
+
+@pytest.mark.gpu
+def test_figfill_devices_two_contexts_on_the_device(tmp_path):
+    """FIGFILL_DEVICES on the MI355X box: two fig_ctx of the real library fill their shards concurrently from two host threads
+    (both on the box's one GPU), merged by the C++ host: the reference's files, byte for byte."""
+    root = util.extract_golden("threads3", str(tmp_path))
+    r = _figfill_devices(root, util.FIGFILL, "0,0")
+    assert r.returncode == 0, r.stderr
+    for fn in util.ref_files(root):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+    root2 = util.extract_golden("bench_b25", str(tmp_path / "b"))
+    r = _figfill_devices(root2, util.FIGFILL, "0,0")
+    assert r.returncode == 0, r.stderr
+    for fn in util.ref_files(root2):
+        assert util.read(os.path.join(root2, "tmp", fn)) == util.read(os.path.join(root2, "ref", fn)), fn
