@@ -585,9 +585,9 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
     const int capacity = std::max(1, c.capacity);      // workgroups the device holds for this class (not capped by the gap count)
     const bool log = getenv("FIG_SCHED_LOG") != nullptr;
     const int minc = getenv("FIG_MIN_CHUNK") ? std::max(1, atoi(getenv("FIG_MIN_CHUNK"))) : 16;      // candidates per gap and round, at least
-    const double ipw = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
+    const double ipw_base = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0;
+    double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0, n_active_max = 0;
     while (true) {
         if ((e = hipMemcpyAsync(ctl, db.gapctl, ctl_n * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
         if ((e = hipStreamSynchronize(stream)) != hipSuccess) return fail(e);
@@ -601,6 +601,13 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
         // early discards at most chunk-1 evaluations.
         long long rem_total = 0;
         for (int g : ids) if (ctl[(size_t)g * 4] == 1) rem_total += std::max(0, ctl[(size_t)g * 4 + 2] - ctl[(size_t)g * 4 + 1]);
+        // Round size: `ipw_base` items per resident workgroup while the lane has about a hundred active gaps (the 512-gap bench
+        // batch: 12 is its optimum), growing with the lane's number of active gaps (its maximum so far) up to 8x.  Measured on one box (round 3,
+        // profiles/round3/largefill_*): the 2048-gap fill of the bench recipe takes 111.9 s with 12 items per workgroup and
+        // round (121 rounds per lane of 1920 items over 385 active gaps: every round ends with a tail of the long items of
+        // the most expensive gaps), 99.8 s with 48 and 98.5 s with 96 -- while 48 costs the 512-gap batch 3 %.
+        n_active_max = std::max(n_active_max, n_active);
+        const double ipw = ipw_base * std::min(8.0, std::max(1.0, n_active_max / 96.0));      // by the lane's largest active set: the rounds stay long to the end of a big fill
         const double share = rem_total > 0 ? (ipw * capacity / (double)std::max(1, c.c.nsplit)) / (double)rem_total : 1.0;
         // Admission: a gap gets at least `minc` candidates in a round it takes part in, and gaps are admitted in cost order
         // until the round is full.  With thousands of active gaps the proportional share alone would hand every gap a few
