@@ -39,6 +39,45 @@ FIG_D unsigned fig_wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
+// ---- log10 for the E-step weights, ~40 FP64 operations against ~105 of the library's (which became a quarter of the E-step's
+// vector work once the chains cost 1.75 operations a step): x = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1) through
+// v_rcp_f64 + one Newton step with the quotient's rounding error recovered (s_lo), log m = 2 s + s z q(z) (atanh series in
+// z = s^2 to z^11), log10 x = e log10(2) + log m log10(e) assembled from hi/lo parts.  Against 80-bit log10l on 3e7 arguments
+// over (0, 1] incl. denormals and the neighbourhood of 1 (tools/ubench/fast_log10_check.c: the same operations on the CPU):
+// max error 1.87 ulp, > 1 ulp in 1.2e-5 of the arguments -- glibc's log10, which the reference calls, is > 1 ulp in 2.3e-4 of
+// them (max 1.58); the two agree bit for bit on 99.44 %.  Exact for 0 (-inf) and 1 (0).  Used for the weights only; the
+// per-read maximum (maxlv) keeps the library's log10.
+FIG_FI double fig_log10_fast(double x) {
+    double m = __builtin_amdgcn_frexp_mant(x);
+    int e = __builtin_amdgcn_frexp_exp(x);
+    const bool lowhalf = m < 0.70710678118654752440;
+    m = lowhalf ? m + m : m; e = lowhalf ? e - 1 : e;
+    const double a = m - 1.0, b = m + 1.0;
+    double r = __builtin_amdgcn_rcp(b);
+    { const double e0 = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e0, r); }
+    const double s = a * r;
+    const double z = s * s;
+    double q = 2.0 / 23.0;
+    q = __builtin_fma(q, z, 2.0 / 21.0); q = __builtin_fma(q, z, 2.0 / 19.0); q = __builtin_fma(q, z, 2.0 / 17.0); q = __builtin_fma(q, z, 2.0 / 15.0);
+    q = __builtin_fma(q, z, 2.0 / 13.0); q = __builtin_fma(q, z, 2.0 / 11.0); q = __builtin_fma(q, z, 2.0 / 9.0); q = __builtin_fma(q, z, 2.0 / 7.0);
+    q = __builtin_fma(q, z, 2.0 / 5.0); q = __builtin_fma(q, z, 2.0 / 3.0);
+    const double s_lo = __builtin_fma(-s, b, a) * r;
+    const double t = s * z * q;
+    const double lm_hi = 2.0 * s;
+    const double lm_lo = __builtin_fma(2.0, s_lo, t);
+    const double L2hi = 0x1.34413509f78p-2, L2lo = 0x1.fef311f12b358p-46;      // log10(2): hi holds 41 bits, e * L2hi is exact
+    const double IE_hi = 0x1.bcb7b1526e50ep-2, IE_lo = 0x1.95355baaafad3p-57;    // log10(e)
+    const double ed = (double)e;
+    const double p_hi = lm_hi * IE_hi;
+    const double p_lo = __builtin_fma(lm_hi, IE_hi, -p_hi) + __builtin_fma(lm_hi, IE_lo, lm_lo * IE_hi);
+    const double r_hi = ed * L2hi;
+    double sum = r_hi + p_hi;
+    double err = (r_hi - sum) + p_hi;
+    if (e == 0) { sum = p_hi; err = 0.0; }
+    const double res = sum + (err + __builtin_fma(ed, L2lo, p_lo));
+    return x == 0.0 ? -__builtin_inf() : res;
+}
+
 // ---- the indexed multiplies.  F0..F7 and the constant 1.0 are pinned to v[232:249]; p* are the products (any registers);
 // w* hold two 16-bit entries of the operand-select stream each: the value M0 takes (0x1000 = "SRC0 is indexed" | register
 // offset 2 * (4 * reverse + base), or 16 = the 1.0 for a slot without a regular read).  Per multiply ONE SALU instruction.
@@ -120,6 +159,7 @@ FIG_FI void fig_sh_chain(double (&p)[FIG_SH_C], const FigPQ *colp, int ncolE, fi
 // Lanes past the last placement (vo false) run on the tile's first placement and store nothing.
 template <int NS>
 FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ *PQ, fig_cu32p stream, double *prow, const int pst, const int o, const bool vo, const int ocalc) {
+    // s0 = first read of the unit, counted from the super-chunk's first read (S.sh_* / prow row index); `stream` = its chunk's rows
     double p[FIG_SH_C];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
@@ -128,7 +168,7 @@ FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ
         p[i] = 1.0;
         if (ocalc >= lo && ocalc <= hi) p[i] = U.insd[tis0 + dir * ocalc];
     }
-    fig_sh_chain<NS>(p, PQ + (ocalc + U.xoff), U.ncolE, stream + (s0 >> 1), (fig_cdp)U.kt_fwd, (fig_cdp)U.kt_rev, U.L);
+    fig_sh_chain<NS>(p, PQ + (ocalc + U.xoff), U.ncolE, stream + ((s0 & (FIG_SH_C - 1)) >> 1), (fig_cdp)U.kt_fwd, (fig_cdp)U.kt_rev, U.L);
     if (vo) {
         double *dst = prow + (long long)s0 * pst + (o + U.L - 1);
 #pragma unroll
@@ -159,36 +199,31 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
     const int pb_c = wave & 3, pb_x0 = (wave >> 2) * CPL * U.wsz + lane;
     unsigned long long fl_acc = 0;
     uint32_t *plb = (uint32_t *)(fig_lds + fig_u(E.off_plb));
-    // tiles of the placement range [-(L-1), G-1] and their deal over the waves: full rounds of nw tiles with all 32 reads,
-    // then the tiles left over split by reads over f waves each
+    // tiles of 64 placements over the range [-(L-1), G-1]
     const int Wn = G + U.L - 1;
     const int nT = (Wn + 63) >> 6;
-    const int nfull = nT / nw, mleft = nT - nfull * nw;
-    int fsplit = 1;
-    if (mleft > 0) { while (fsplit * 2 * mleft <= nw && fsplit < 8) fsplit *= 2; }
-    const int nsl = FIG_SH_C / fsplit;                         // reads per wave in the split round
-    const bool has_left = mleft > 0 && wave < mleft * fsplit;
-    const int tile_left = nfull * nw + wave / fsplit, s0_left = (wave % fsplit) * nsl;
     FIG_SYNC();                                                // placeReads zeroed countsGap already (:3050-3056)
     FIG_T0(E);
-    for (int c0 = 0; c0 < nU; c0 += FIG_SH_C) {
-        // ---- insert-size windows and packed-read offsets of the chunk's reads
-        if (tid < 64) {
+    for (int c0 = 0; c0 < nU; c0 += FIG_SH_SC * FIG_SH_C) {
+        // ---- a super-chunk: up to FIG_SH_SC chunks of 32 reads.  Insert-size windows and packed-read offsets of its reads
+        const int nrd = nU - c0 < FIG_SH_SC * FIG_SH_C ? nU - c0 : FIG_SH_SC * FIG_SH_C;
+        const int nc = (nrd + FIG_SH_C - 1) / FIG_SH_C;
+        if (tid < FIG_SH_SC * FIG_SH_C) {
             const int r = c0 + tid;
             int lo = 0, hi = -1, tis0 = 0, dir = 1; bool irr = false;
             int len = 0, aux = 0; long long woff = 0;
-            if (tid < FIG_SH_C && r < nU) {
+            if (r < nU) {
                 len = U.u_len[ub + r]; aux = U.u_aux[ub + r]; woff = U.u_woff[ub + r];
                 const FigWin w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
                 lo = w.lo; hi = w.hi; tis0 = w.tis0; dir = w.dir;
                 irr = ((aux >> 1) & 1) != 0 || len != U.L;
             }
-            if (tid < FIG_SH_C) { S.sh_lo[tid] = lo; S.sh_hi[tid] = hi; S.sh_tis0[tid] = tis0; S.sh_dir[tid] = dir; S.sh_len[tid] = len; S.sh_aux[tid] = aux; S.sh_woff[tid] = woff; }
+            S.sh_lo[tid] = lo; S.sh_hi[tid] = hi; S.sh_tis0[tid] = tis0; S.sh_dir[tid] = dir; S.sh_len[tid] = len; S.sh_aux[tid] = aux; S.sh_woff[tid] = woff;
             const unsigned long long im = fig_ballot(irr);
-            if (tid == 0) S.sh_irr = (unsigned)(im & 0xffffffffULL);
+            if (lane == 0) { S.sh_irr[2 * wave] = (unsigned)(im & 0xffffffffULL); S.sh_irr[2 * wave + 1] = (unsigned)(im >> 32); }
         }
         FIG_SYNC();
-        // position lists of the chunk's first row group: fetched now, parked in plb when the group starts (wave t: row t)
+        // position lists of the first row group: fetched now, parked in plb when the group starts (wave t: row t)
         uint32_t plv_next = 0;
         if (wave < NR && c0 + wave < nU) {
             const int len = fig_u(S.sh_len[wave]);
@@ -196,20 +231,34 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
             if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
         }
         FIG_TICK(E, 34);
-        // ---- phase A: lanes = placements, the raw products of all reads of the chunk -> prow
-        const fig_cu32p stc = stream0 + (long long)(c0 / FIG_SH_C) * U.L * (FIG_SH_C / 2);
-        for (int k = 0; k < nfull; k++) {
-            const int ob = -(U.L - 1) + 64 * (k * nw + wave), o = ob + lane;
-            const bool vo = o <= G - 1;
-            fig_sh_unit<32>(0, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
-        }
-        if (has_left) {
-            const int ob = -(U.L - 1) + 64 * tile_left, o = ob + lane;
-            const bool vo = o <= G - 1;
-            if (fsplit == 1) fig_sh_unit<32>(0, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
-            else if (fsplit == 2) fig_sh_unit<16>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
-            else if (fsplit == 4) fig_sh_unit<8>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
-            else fig_sh_unit<4>(s0_left, S, U, PQ, stc, prow, pst, o, vo, vo ? o : ob);
+        // ---- phase A: lanes = placements, the raw products of all reads -> prow.  Work items = (chunk, tile) pairs: full
+        // rounds of nw items with all 32 reads of their chunk; the items left over are split by reads over f waves each.
+        {
+            const int nit = nT * nc;
+            const int nfull = nit / nw, mleft = nit - nfull * nw;
+            const fig_cu32p stc = stream0 + (long long)(c0 / FIG_SH_C) * U.L * (FIG_SH_C / 2);
+            for (int k = 0; k < nfull; k++) {
+                const int it = k * nw + wave, ci = it / nT, tl = it - ci * nT;
+                const int ob = -(U.L - 1) + 64 * tl, o = ob + lane;
+                const bool vo = o <= G - 1;
+                fig_sh_unit<32>(ci * FIG_SH_C, S, U, PQ, stc + (long long)ci * U.L * (FIG_SH_C / 2), prow, pst, o, vo, vo ? o : ob);
+            }
+            if (mleft > 0) {
+                int fsplit = 1;
+                while (fsplit * 2 * mleft <= nw && fsplit < 8) fsplit *= 2;
+                if (wave < mleft * fsplit) {
+                    const int nsl = FIG_SH_C / fsplit;                 // reads per wave in the split round
+                    const int it = nfull * nw + wave / fsplit, ci = it / nT, tl = it - ci * nT;
+                    const int s0 = ci * FIG_SH_C + (wave % fsplit) * nsl;
+                    const int ob = -(U.L - 1) + 64 * tl, o = ob + lane;
+                    const bool vo = o <= G - 1;
+                    const fig_cu32p stp = stc + (long long)ci * U.L * (FIG_SH_C / 2);
+                    if (fsplit == 1) fig_sh_unit<32>(s0, S, U, PQ, stp, prow, pst, o, vo, vo ? o : ob);
+                    else if (fsplit == 2) fig_sh_unit<16>(s0, S, U, PQ, stp, prow, pst, o, vo, vo ? o : ob);
+                    else if (fsplit == 4) fig_sh_unit<8>(s0, S, U, PQ, stp, prow, pst, o, vo, vo ? o : ob);
+                    else fig_sh_unit<4>(s0, S, U, PQ, stp, prow, pst, o, vo, vo ? o : ob);
+                }
+            }
         }
         FIG_TICK(E, 35);
         FIG_SYNC();                                            // every wave's products are in prow
@@ -220,8 +269,8 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
         for (int t = 0; t < NR; t++)
 #pragma unroll
             for (int k = 0; k < KP; k++) { const int i = tid + k * U.nt; pn[t][k] = (i < Wn && c0 + t < nU) ? prow[(long long)t * pst + i] : 0.0; }
-        for (int q0 = 0; q0 < FIG_SH_C && c0 + q0 < nU; q0 += NR) {
-            const unsigned irr = (unsigned)fig_u((int)S.sh_irr);
+        for (int q0 = 0; q0 < nrd; q0 += NR) {
+            const unsigned irr = (unsigned)fig_u((int)S.sh_irr[q0 >> 5]) >> (q0 & 31);      // bits 0..NR-1: the group's reads
             // the group's scalars, all four rows at once (lane t of every wave reads row t's, v_readlane hands them round)
             int g_lo = 0, g_hi = -1, g_len = 0;
             if (lane < NR && c0 + q0 + lane < nU) { g_lo = S.sh_lo[q0 + lane]; g_hi = S.sh_hi[q0 + lane]; g_len = S.sh_len[q0 + lane]; }
@@ -229,7 +278,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 plb[wave * 64 + lane] = plv_next;              // fetched while the previous group ran
                 plv_next = 0;
                 const int sn = q0 + NR + wave;                 // the same row of the next group of this chunk
-                if (sn < FIG_SH_C && c0 + sn < nU) {
+                if (sn < nrd) {
                     const int len = fig_u(S.sh_len[sn]);
                     const int ndw = 2 + ((len + 3) >> 2) + 4;
                     if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
@@ -247,7 +296,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 if (r >= nU) continue;
                 const int lo = __builtin_amdgcn_readlane(g_lo, t), hi = __builtin_amdgcn_readlane(g_hi, t);
                 double *wrow = W + (long long)t * Wcap + (U.L - 1);
-                const bool isirr = (irr >> s) & 1u;
+                const bool isirr = (irr >> t) & 1u;
                 if (hi < lo) continue;
                 if (!isirr) {
                     // weights of this read's placements: w = exp(0.5 log10 p) inside the read's window, 0 outside (:3591-3601);
@@ -259,7 +308,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                         const int i = tid + k * U.nt, o = i - (U.L - 1);
                         if (k * U.nt + wave * 64 < Wn) {        // (wave-uniform: a wave without placements in this pass skips it)
                             const bool in = i < Wn && o >= lo && o <= hi;
-                            const double tl = fig_log10(pc[t][k]);
+                            const double tl = fig_log10_fast(pc[t][k]);
                             const double wv = fig_exp(0.5 * tl);
                             if (i < Wn) wrow[o] = in ? wv : 0.0;
                             if (in) {
@@ -311,7 +360,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
             FIG_SYNC();
             FIG_TICK(E, 37);
             // the next group's products (their latency hides behind this group's column pass)
-            if (q0 + NR < FIG_SH_C && c0 + q0 + NR < nU) {
+            if (q0 + NR < nrd) {
 #pragma unroll
                 for (int t = 0; t < NR; t++)
 #pragma unroll
@@ -322,7 +371,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
             if (tid >= 64 && tid < 64 + NR) {
                 const int t = tid - 64, s = q0 + t;
                 if (c0 + s < nU) {
-                    const bool isirr = (irr >> s) & 1u;
+                    const bool isirr = (irr >> t) & 1u;
                     FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
                     if (S.sh_hi[s] >= S.sh_lo[s]) for (int k = 0; k < nw; k++) { FigBest y; y.v = S.wv_v[t * 8 + k]; y.o = S.wv_o[t * 8 + k]; b = fig_best_merge(b, y); }
                     if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + s] = isirr ? b.v : fig_log10(b.v);
@@ -416,7 +465,7 @@ FIG_D bool fig_sh_applies(const FigEng &E, int cpl) {
     const FigState &S = *E.S;
     if (S.left < E.xoff) return false;
     const int Wn = S.G + E.M->L - 1;
-    return Wn <= 2 * E.nt && (E.nw == 4 || E.nw == 8) && (long long)FIG_SH_C * E.Wcap <= (long long)E.B->capW;
+    return Wn <= 2 * E.nt && (E.nw == 4 || E.nw == 8) && (long long)FIG_SH_SC * FIG_SH_C * E.Wcap <= (long long)E.B->capW;
 }
 
 #endif  // !FIG_EMU

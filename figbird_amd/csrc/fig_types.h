@@ -15,6 +15,7 @@
 #define FIG_FLANK 208                // flank window kept per side: >= max(read length, side_limit=30)
 #define FIG_DBL_MAX 1.7976931348623157e308
 #define FIG_SH_C 32                  // reads per chunk of the shared-factor E-step (fig_engine_shared.h)
+#define FIG_SH_SC 4                  // chunks per super-chunk: the (chunk, tile) work items of phase A are dealt over the waves per super-chunk
 #define FIG_SH_ONE 16                // operand-select register offset of the constant 1.0 (slots without a regular read)
 #define FIG_MLE_FB 208               // doubles of the per-wave factor buffer of the MLE pass (>= FIG_MAX_READLEN)
 // LDS-tiled class: doubles of LDS the MLE pass needs to run its LDS form over all ncolE columns: C[5][ncolE], one 16-byte

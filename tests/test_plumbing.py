@@ -105,3 +105,24 @@ def test_preprocess_boundary_golden(lib, tmp_path):
 def test_preprocess_live_against_reference(seed, tmp_path):
     from tools.compare_prep import run_one
     assert run_one(seed, str(tmp_path), verbose=False, end_gap=(seed % 3 == 0), n_contigs=1 + seed % 3, n_frag=900, n_jump=900)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/RunFigbird.sh"), reason="needs the reference's driver script (this container only)")
+def test_driver_patch_applies_to_the_reference_script(tmp_path):
+    """integration/RunFigbird.patch -- the edits INTEGRATION.md §1/§4b describe (every `g++ X.cpp && ./a.out` and
+    `python reference.py` of the gap-fill pipeline re-pointed at figfill / figtool) -- applies cleanly to the reference's
+    RunFigbird.sh, leaves a script bash parses, and touches nothing but those 14 command lines (+ the FIGBIRD_AMD guard)."""
+    import shutil, subprocess
+    dst = tmp_path / "RunFigbird.sh"
+    shutil.copy("/root/reference/RunFigbird.sh", dst)
+    patch = os.path.join(util.ROOT, "integration", "RunFigbird.patch")
+    r = subprocess.run(["patch", "-s", str(dst), patch], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert subprocess.run(["bash", "-n", str(dst)]).returncode == 0
+    new = dst.read_text().split("\n"); old = open("/root/reference/RunFigbird.sh").read().split("\n")
+    assert len(new) == len(old) + 2
+    changed = [i for i in range(len(old)) if old[i] != new[i + 2 if i >= 2 else i]]
+    assert [i + 1 for i in changed] == [254, 256, 266, 285, 320, 338, 352, 433, 435, 451, 472, 480, 777, 809]
+    txt = "\n".join(new)
+    assert txt.count('"$FIGBIRD_AMD/bin/figfill"') == 2 and txt.count('"$FIGBIRD_AMD/bin/figtool"') == 12
+    assert "g++ -std=c++11 -pthread FillGaps.cpp" not in txt and "g++ Preprocess.cpp" not in txt
