@@ -446,6 +446,8 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
         c.capacity = ctx->n_cu * per_cu;
         c.blocks = std::min<int>(lc.q_end - lc.q_begin, c.capacity);
         max_blocks = std::max(max_blocks, c.capacity);
+        if (getenv("FIG_SCHED_LOG")) fprintf(stderr, "[figsched] class: capG=%d capGl=%d ncolE=%d Wcap=%d nt=%d nteams=%d lds_tab=%d tiles=%d tile_cols=%d lds=%zu gaps=%d per_cu=%d blocks=%d (FigState %zu B)\n",
+                                             lc.capG, lc.capGl, lc.ncolE, lc.Wcap, lc.nt, lc.nteams, (int)lc.lds_tab, lc.tiles, lc.tile_cols, lc.lds, lc.q_end - lc.q_begin, per_cu, c.blocks, sizeof(FigState));
         ctx->classes.push_back(c);
     }
     int capG_s = K.capG, capR = K.capR, capP = K.capP, capC = K.capC;
@@ -522,7 +524,10 @@ static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     A.capG = c.c.capG; A.capGl = c.c.capGl; A.ncolE = c.c.ncolE; A.Wcap = c.c.Wcap; A.nteams = c.c.nteams;
     A.q_begin = c.c.q_begin; A.q_end = c.c.q_end; A.qsel = 0;
     A.tiles = c.c.tiles; A.tile_step = c.c.tile_step; A.tile_cols = c.c.tile_cols; A.tiled_max = c.c.tiled_max;
-    { const char *ev = getenv("FIG_ESTEP"); A.sh_on = !(ev && !strcmp(ev, "pair")); }      // FIG_ESTEP=pair: the pair-chain E-step everywhere (A/B runs, tests)
+    // FIG_ESTEP=pair: the pair-chain E-step everywhere (A/B runs, tests); FIG_SH_CHUNKS=<1..4>: chunks per super-chunk of the
+    // shared-factor E-step (fig_engine_shared.h; default 4: bench step 24.3 s with 2, 23.9 s with 4)
+    { const char *ev = getenv("FIG_ESTEP"); const char *sc = getenv("FIG_SH_CHUNKS");
+      A.sh_on = (ev && !strcmp(ev, "pair")) ? 0 : (sc ? std::max(1, std::min(FIG_SH_SC, atoi(sc))) : FIG_SH_SC); }
     return A;
 }
 

@@ -149,8 +149,10 @@ struct FigState {
     int tm_aux[16]; long long tm_woff[16];   // LDS-tiled class: the chunk's read scalars, staged once per chunk
     double wv_v[32]; int wv_o[32];   // per-wave partial arg-max ([team][wave of the team]; LDS-tiled class: [read of the chunk][wave])
     // shared-factor E-step (fig_engine_shared.h): insert-size windows of the chunk's 32 reads; reads that take the generic chain
-    int sh_lo[FIG_SH_SC * FIG_SH_C], sh_hi[FIG_SH_SC * FIG_SH_C], sh_tis0[FIG_SH_SC * FIG_SH_C], sh_dir[FIG_SH_SC * FIG_SH_C], sh_len[FIG_SH_SC * FIG_SH_C], sh_aux[FIG_SH_SC * FIG_SH_C];
-    long long sh_woff[FIG_SH_SC * FIG_SH_C];
+    short sh_lo[FIG_SH_SC * FIG_SH_C], sh_hi[FIG_SH_SC * FIG_SH_C];      // (the shared form is taken for <= 1024 placements only)
+    int sh_tis0[FIG_SH_SC * FIG_SH_C];
+    unsigned sh_woff[FIG_SH_SC * FIG_SH_C];                              // packed-read word offset relative to the gap's first read
+    unsigned char sh_len[FIG_SH_SC * FIG_SH_C], sh_aux[FIG_SH_SC * FIG_SH_C];   // aux: bit 0 reverse, bit 1 N base, bit 2 window direction +1
     unsigned sh_irr[16], sh_pad;        // [chunk of the super-chunk] (two per staging wave)
     int mle_next, pad_mn;            // next read of the MLE pass (waves take reads dynamically)
     int fin_i[8];                    // finalize statistics (flags / max / counts), filled with atomics

@@ -164,7 +164,7 @@ FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         const int s = s0 + i;
-        const int lo = fig_u(S.sh_lo[s]), hi = fig_u(S.sh_hi[s]), tis0 = fig_u(S.sh_tis0[s]), dir = fig_u(S.sh_dir[s]);
+        const int lo = fig_u(S.sh_lo[s]), hi = fig_u(S.sh_hi[s]), tis0 = fig_u(S.sh_tis0[s]), dir = (fig_u(S.sh_aux[s]) & 4) ? 1 : -1;
         p[i] = 1.0;
         if (ocalc >= lo && ocalc <= hi) p[i] = U.insd[tis0 + dir * ocalc];
     }
@@ -191,6 +191,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
     const int Wcap = U.Wcap;
     const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid, nw = U.nw;
     const fig_cu32p stream0 = (fig_cu32p)(fig_uptr(fig_uptr(E.B)->ustream) + fig_u64(fig_uptr(E.g)->streamOff));
+    const long long wbase = nU > 0 ? fig_u64(U.u_woff[ub]) : 0;     // packed-read offsets are kept relative to the gap's first read
     double *prow = fig_uptr(E.scr.wg);                        // raw products of the chunk: [32 reads][pst] (scratch slab, L2)
     const int pst = Wcap;
     double acc[CPL];
@@ -202,23 +203,27 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
     // tiles of 64 placements over the range [-(L-1), G-1]
     const int Wn = G + U.L - 1;
     const int nT = (Wn + 63) >> 6;
+    // Chunks per super-chunk (at most E.sh_on <= FIG_SH_SC): more chunks deal the (chunk, tile) items more evenly over the waves
+    int scn = fig_u(E.sh_on);
+    scn = scn < 1 ? 1 : (scn > FIG_SH_SC ? FIG_SH_SC : scn);
     FIG_SYNC();                                                // placeReads zeroed countsGap already (:3050-3056)
     FIG_T0(E);
-    for (int c0 = 0; c0 < nU; c0 += FIG_SH_SC * FIG_SH_C) {
-        // ---- a super-chunk: up to FIG_SH_SC chunks of 32 reads.  Insert-size windows and packed-read offsets of its reads
-        const int nrd = nU - c0 < FIG_SH_SC * FIG_SH_C ? nU - c0 : FIG_SH_SC * FIG_SH_C;
+    for (int c0 = 0; c0 < nU; c0 += scn * FIG_SH_C) {
+        // ---- a super-chunk: up to scn chunks of 32 reads.  Insert-size windows and packed-read offsets of its reads
+        const int nrd = nU - c0 < scn * FIG_SH_C ? nU - c0 : scn * FIG_SH_C;
         const int nc = (nrd + FIG_SH_C - 1) / FIG_SH_C;
         if (tid < FIG_SH_SC * FIG_SH_C) {
             const int r = c0 + tid;
             int lo = 0, hi = -1, tis0 = 0, dir = 1; bool irr = false;
             int len = 0, aux = 0; long long woff = 0;
-            if (r < nU) {
+            if (tid < nrd) {
                 len = U.u_len[ub + r]; aux = U.u_aux[ub + r]; woff = U.u_woff[ub + r];
                 const FigWin w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
                 lo = w.lo; hi = w.hi; tis0 = w.tis0; dir = w.dir;
                 irr = ((aux >> 1) & 1) != 0 || len != U.L;
             }
-            S.sh_lo[tid] = lo; S.sh_hi[tid] = hi; S.sh_tis0[tid] = tis0; S.sh_dir[tid] = dir; S.sh_len[tid] = len; S.sh_aux[tid] = aux; S.sh_woff[tid] = woff;
+            S.sh_lo[tid] = (short)lo; S.sh_hi[tid] = (short)hi; S.sh_tis0[tid] = tis0; S.sh_len[tid] = (unsigned char)len;
+            S.sh_aux[tid] = (unsigned char)((aux & 3) | (dir > 0 ? 4 : 0)); S.sh_woff[tid] = (unsigned)(woff - wbase);
             const unsigned long long im = fig_ballot(irr);
             if (lane == 0) { S.sh_irr[2 * wave] = (unsigned)(im & 0xffffffffULL); S.sh_irr[2 * wave + 1] = (unsigned)(im >> 32); }
         }
@@ -228,7 +233,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
         if (wave < NR && c0 + wave < nU) {
             const int len = fig_u(S.sh_len[wave]);
             const int ndw = 2 + ((len + 3) >> 2) + 4;
-            if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+            if (lane < ndw) plv_next = U.packed[wbase + fig_u((int)S.sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
         }
         FIG_TICK(E, 34);
         // ---- phase A: lanes = placements, the raw products of all reads -> prow.  Work items = (chunk, tile) pairs: full
@@ -281,7 +286,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 if (sn < nrd) {
                     const int len = fig_u(S.sh_len[sn]);
                     const int ndw = 2 + ((len + 3) >> 2) + 4;
-                    if (lane < ndw) plv_next = U.packed[fig_u64(S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+                    if (lane < ndw) plv_next = U.packed[wbase + fig_u((int)S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
                 }
             }
             if (tid < NR) { S.tm_lo[tid] = g_lo; S.tm_hi[tid] = g_hi; S.tm_len[tid] = g_len; }
@@ -333,12 +338,12 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                     }
                 } else {
                     // generic chain (N bases / short read): all lanes over the read's window, zero outside it
-                    FigReadS rs; rs.len = fig_u(S.sh_len[s]); rs.rev = fig_u(S.sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = fig_u64(S.sh_woff[s]);
+                    FigReadS rs; rs.len = fig_u(S.sh_len[s]); rs.rev = fig_u(S.sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = wbase + fig_u((int)S.sh_woff[s]);
                     fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
                     const int nw2 = (rs.len + 15) >> 4;
                     fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
                     const double *Q4 = fig_q4_ptr<LDS>(E);
-                    const int tis0 = fig_u(S.sh_tis0[s]), dir = fig_u(S.sh_dir[s]);
+                    const int tis0 = fig_u(S.sh_tis0[s]), dir = (fig_u(S.sh_aux[s]) & 4) ? 1 : -1;
                     for (int i = -(U.L - 1) + tid; i < G; i += U.nt) if (i < lo || i > hi) wrow[i] = 0.0;
                     FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
                     unsigned long long nplace = 0, nadd = 0;

@@ -278,7 +278,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         }
         K.capE = std::max(K.capE, c.ncolE);
         K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);
-        if (m->unmapped_flag && c.lds_tab && !c.tiles && c.nteams >= 4) K.capW = std::max(K.capW, FIG_SH_SC * FIG_SH_C * c.Wcap + 1024);   // product rows of the shared-factor E-step (fig_engine_shared.h)   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
+        if (m->unmapped_flag && c.lds_tab && !c.tiles && c.nteams >= 4) K.capW = std::max(K.capW, (getenv("FIG_CAPW_SCALE") ? atoi(getenv("FIG_CAPW_SCALE")) : 1) * FIG_SH_SC * FIG_SH_C * c.Wcap + 1024);   // product rows of the shared-factor E-step (fig_engine_shared.h)   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
     }
     return FIG_OK;
 }
