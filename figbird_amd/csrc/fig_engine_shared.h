@@ -112,45 +112,54 @@ FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t 
 // The loads of step j + 1 (four ds_read_b128, the stream row, the {1-e, e} pairs of both orientations) are issued before
 // the arithmetic of step j.  (A scalar load that misses the scalar cache comes back from L2 in ~190 cycles against ~135 on
 // a hit, tools/ubench/kcache.hip: one step of arithmetic covers either.)
+// One chain step: issue the loads of step jn (four ds_read_b128, the stream row, the {1-e, e} pairs of both orientations)
+// into the `n` set, then the eight factors and NS indexed multiplies of the current step from the `c` set.
+template <int NS>
+FIG_FI void fig_sh_step(double (&p)[FIG_SH_C], const uint32_t (&wc)[NS / 2], const double (&kc)[4], const FigPQ (&ac)[4],
+                        uint32_t (&wn)[NS / 2], double (&kn)[4], FigPQ (&an)[4], const FigPQ *colp, int ncolE, fig_cu32p st, fig_cdp ktf, fig_cdp ktr, int jn) {
+    {
+        fig_cu32p sn = st + jn * (FIG_SH_C / 2);
+#pragma unroll
+        for (int k = 0; k < NS / 2; k++) wn[k] = sn[k];
+        kn[0] = ktf[2 * jn]; kn[1] = ktf[2 * jn + 1]; kn[2] = ktr[2 * jn]; kn[3] = ktr[2 * jn + 1];
+        const FigPQ *cn = colp + jn;
+#pragma unroll
+        for (int b = 0; b < 4; b++) an[b] = cn[b * ncolE];
+    }
+    double f[8];
+#pragma unroll
+    for (int b = 0; b < 4; b++) {
+        f[b] = ac[b].p * kc[0] + kc[1] * ac[b].q;           // forward reads: {1-e[j], e[j]}          (:3581-3589)
+        f[4 + b] = ac[b].p * kc[2] + kc[3] * ac[b].q;       // reverse reads: {1-e[L-1-j], e[L-1-j]}  (:3569-3576)
+    }
+    const double one = 1.0;
+    if (NS == 32) { fig_sh_mul16(&p[0], f, one, &wc[0]); fig_sh_mul16(&p[16], f, one, &wc[8]); }
+    else if (NS == 16) fig_sh_mul16(&p[0], f, one, &wc[0]);
+    else if (NS == 8) fig_sh_mul8(&p[0], f, one, &wc[0]);
+    else fig_sh_mul4(&p[0], f, one, &wc[0]);
+}
+
+// ---- the chain: NS products per lane over the L steps of the chunk.  colp = PQ + x (x = o + xoff: the lane's first column),
+// st = the chunk's stream row of step 0 at this wave's first slot (16 dwords per step; one padded row behind the last).
+// The loads of step j + 1 are issued before the arithmetic of step j; two register sets take turns (no copies).  (A scalar
+// load that misses the scalar cache comes back from L2 in ~190 cycles against ~135 on a hit, tools/ubench/kcache.hip: one
+// step of arithmetic covers either.)
 template <int NS>
 FIG_FI void fig_sh_chain(double (&p)[FIG_SH_C], const FigPQ *colp, int ncolE, fig_cu32p st, fig_cdp ktf, fig_cdp ktr, int L) {
-    uint32_t wn[NS / 2];
-    double kn[4];
-    FigPQ an[4];
+    uint32_t w0[NS / 2], w1[NS / 2];
+    double k0[4], k1[4];
+    FigPQ a0[4], a1[4];
 #pragma unroll
-    for (int k = 0; k < NS / 2; k++) wn[k] = st[k];
-    kn[0] = ktf[0]; kn[1] = ktf[1]; kn[2] = ktr[0]; kn[3] = ktr[1];
+    for (int k = 0; k < NS / 2; k++) w0[k] = st[k];
+    k0[0] = ktf[0]; k0[1] = ktf[1]; k0[2] = ktr[0]; k0[3] = ktr[1];
 #pragma unroll
-    for (int b = 0; b < 4; b++) an[b] = colp[b * ncolE];
-    const double one = 1.0;
-    for (int j = 0; j < L; j++) {
-        uint32_t w[NS / 2];
-        double kk[4];
-        FigPQ a[4];
-#pragma unroll
-        for (int k = 0; k < NS / 2; k++) w[k] = wn[k];
-#pragma unroll
-        for (int k = 0; k < 4; k++) { kk[k] = kn[k]; a[k] = an[k]; }
-        {
-            fig_cu32p sn = st + (j + 1) * (FIG_SH_C / 2);
-#pragma unroll
-            for (int k = 0; k < NS / 2; k++) wn[k] = sn[k];
-            kn[0] = ktf[2 * j + 2]; kn[1] = ktf[2 * j + 3]; kn[2] = ktr[2 * j + 2]; kn[3] = ktr[2 * j + 3];
-            const FigPQ *cn = colp + (j + 1);
-#pragma unroll
-            for (int b = 0; b < 4; b++) an[b] = cn[b * ncolE];
-        }
-        double f[8];
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-            f[b] = a[b].p * kk[0] + kk[1] * a[b].q;           // forward reads: {1-e[j], e[j]}          (:3581-3589)
-            f[4 + b] = a[b].p * kk[2] + kk[3] * a[b].q;       // reverse reads: {1-e[L-1-j], e[L-1-j]}  (:3569-3576)
-        }
-        if (NS == 32) { fig_sh_mul16(&p[0], f, one, &w[0]); fig_sh_mul16(&p[16], f, one, &w[8]); }
-        else if (NS == 16) fig_sh_mul16(&p[0], f, one, &w[0]);
-        else if (NS == 8) fig_sh_mul8(&p[0], f, one, &w[0]);
-        else fig_sh_mul4(&p[0], f, one, &w[0]);
+    for (int b = 0; b < 4; b++) a0[b] = colp[b * ncolE];
+    int j = 0;
+    for (; j + 2 <= L; j += 2) {
+        fig_sh_step<NS>(p, w0, k0, a0, w1, k1, a1, colp, ncolE, st, ktf, ktr, j + 1);
+        fig_sh_step<NS>(p, w1, k1, a1, w0, k0, a0, colp, ncolE, st, ktf, ktr, j + 2);
     }
+    if (j < L) fig_sh_step<NS>(p, w0, k0, a0, w1, k1, a1, colp, ncolE, st, ktf, ktr, j + 1);
 }
 
 // One unit = (tile of 64 placements, NS reads [s0, s0 + NS) of the chunk): products start from the insert-size terms
