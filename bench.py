@@ -424,6 +424,18 @@ def read_brackets():
         return {"source": f"unavailable: {e!r}"}
 
 
+def csrc_sha():
+    """Content hash of the kernel sources (figbird_amd/csrc/*.h, *.hip): ties profiles/traffic_sidecar.json to the build it was
+    measured on without needing git (the GPU boxes have no .git)."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(ROOT, "figbird_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".h", ".hip")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()[:12]
+
+
 def read_traffic(args, world):
     """HBM bytes per step from the PMC passes of this same command (tools/profile_bench.sh writes the sidecar from
     `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters cannot be read from inside the process)."""
@@ -438,12 +450,8 @@ def read_traffic(args, world):
                 return e1["bytes_per_step"] * world, e1.get("note", "") + f" x {world} ranks, scaled from the 1-GPU PMC pass (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
         if ent:
             stale = ""
-            try:
-                head = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True, timeout=5).stdout.strip()
-                if head and sc.get("head") and head != sc.get("head"):
-                    stale = f"; STALE: recorded at head {sc.get('head')}, this is {head}"
-            except Exception:
-                pass
+            if sc.get("csrc_sha") and sc.get("csrc_sha") != csrc_sha():
+                stale = "; STALE: the PMC passes were recorded with other kernel sources (csrc hash differs)"
             return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')}{stale})"
         return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"
     except Exception as e:

@@ -8,7 +8,7 @@ TAG=${1:-r2}
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-ARGS="--steps 1 --warmup 0 --cpu-baseline 0 --partial-pass 0"
+ARGS="--steps 1 --warmup 0 --cpu-baseline 0 --partial-pass 0 --bracket-probes 0"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $OUT/stats -o run -- python3 bench.py $ARGS > $OUT/bench_stats.json 2> $OUT/bench_stats.err
 echo stats done > $OUT/progress.txt
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- python3 bench.py $ARGS > $OUT/bench_pmc_fetch.json 2> $OUT/bench_pmc_fetch.err

@@ -55,7 +55,9 @@ def main():
     if "bytes_per_step" in traffic:
         # the sidecar bench.py reads roofline.traffic from (copy to profiles/traffic_sidecar.json): keyed like bench.workload_key()
         # for the default command the passes above ran
-        side = {"head": os.environ.get("FIG_HEAD", tag),
+        sys.path.insert(0, os.path.dirname(here))
+        import bench
+        side = {"head": os.environ.get("FIG_HEAD", tag), "csrc_sha": bench.csrc_sha(),
                 "unmapped|gage|g512|r1000|s20260101|n1": {"bytes_per_step": traffic["bytes_per_step"], "fetch_bytes_raw": traffic["fetch"]["bytes_per_fill_raw"],
                                                           "write_bytes": traffic["write"]["bytes_per_fill_raw"], "note": traffic["note"]}}
         json.dump(side, open(os.path.join(sm, "traffic_sidecar.json"), "w"), indent=1)

@@ -54,8 +54,9 @@ def main():
     os.makedirs(os.path.join(d, "gaps"), exist_ok=True)
     open(os.path.join(d, "tmp", "gaploads.txt"), "w").write("\n")
     fig_argv = ["scf.fa", str(int(jump[0] * 1.15)), str(L), "1", "0", "1", "0", "0", "tmp/myout.sam", "tmp/", "gaps/", "30", str(L), "400", "0"]
+    print("[host] " + json.dumps(line), flush=True)
     t0 = time.time(); r = subprocess.run([os.path.join(REF, "Figbird.out")] + fig_argv, cwd=d, capture_output=True, text=True); t_ref = time.time() - t0
-    assert r.returncode == 0, r.stderr[-300:]
+    ref_ok = r.returncode == 0          # (the reference's worker process dies on some large inputs: recorded, not fatal here)
     tm = {}
     for thr in (1, os.cpu_count() or 8):
         os.environ["FIGFILL_THREADS"] = str(thr)
@@ -63,7 +64,7 @@ def main():
         api.model_from_files(os.path.join(d, "scf.fa"), os.path.join(d, "tmp") + "/", myout, partial_flag=0, unmapped_flag=1, script_itr=1,
                              max_distance=int(jump[0] * 1.15), read_length=L, neg_overlap=30, partial_len=L)
         tm[thr] = time.time() - t0
-    line["n2_model_build"] = {"myout_records": n_my, "reference_worker_process_s": round(t_ref, 2),
+    line["n2_model_build"] = {"myout_records": n_my, "reference_worker_process_s": round(t_ref, 2) if ref_ok else None, "reference_worker_process_rc": r.returncode,
                               "note": "reference: one Figbird.cpp worker process with no gap to fill (scaffold + myout.sam parse + model), repeated by each of its $num_threads processes",
                               **{f"build_model_{k}_threads_s": round(v, 2) for k, v in tm.items()}}
     print("[host] " + json.dumps(line), flush=True)
