@@ -411,15 +411,15 @@ def bracket_probes(args, eng, main_batch, spec, budget_s):
 def read_brackets():
     """Per-bracket figures (SURVEY §8d asks for gaps/s per bracket beside the blended number): the batches of 512 equal gaps
     are too long to run inside this command's budget, so the line carries the latest committed probe of the same build
-    (tools/gpu_probe.py -> profiles/round2/probe512_final.txt), labelled as such."""
-    path = os.path.join(ROOT, "profiles", "round2", "probe512_final.txt")
+    (tools/gpu_probe.py -> profiles/round3/probe512_final.txt), labelled as such."""
+    path = os.path.join(ROOT, "profiles", "round3", "probe512_final.txt")
     try:
         rows = []
         for ln in open(path):
             if ln.startswith("{"):
                 d = json.loads(ln)
                 rows.append({"gap_bp": d["G"], "gaps_per_s": d["gaps_per_s"], "tflops": d["tflops"], "frac_of_fp64_nofma_peak": round(d["tflops"] / FP64_NOFMA_PEAK_TFLOPS, 4)})
-        return {"source": "profiles/round2/probe512_final.txt (tools/gpu_probe.py unmapped <G> 512: 512 equal gaps, ~1000 reads each, kernel time of one fill; not measured in this run)", "unmapped": rows}
+        return {"source": "profiles/round3/probe512_final.txt (tools/gpu_probe.py unmapped <G> 512: 512 equal gaps, ~1000 reads each, kernel time of one fill; not measured in this run)", "unmapped": rows}
     except Exception as e:
         return {"source": f"unavailable: {e!r}"}
 
