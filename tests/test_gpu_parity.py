@@ -125,6 +125,15 @@ def test_bench_regime_candidates_and_planes_match_the_pinned_oracle(name, tmp_pa
         assert abs(float(ref["stats"][1]) - st["alg_flops"]) <= 1e-9 * float(ref["stats"][1])
 
 
+@pytest.mark.parametrize("seed", [701, 702, 703])
+def test_gpu_fuzz_mid_bracket_against_oracle(seed, tmp_path):
+    """Fresh seeded unmapped gaps of the 134-400 bracket (candidates 0.5 G0 .. 2.5 G0: hundreds of candidate lengths through
+    the speculative scheduler and its early-stop replay), which the general fuzz generator leaves out for its CPU cost."""
+    from tools.fuzz_ref import mk_mid
+    from tools.compare_emu import run_one
+    assert run_one(mk_mid(seed), str(tmp_path), exe=util.FIGFILL, verbose=False)
+
+
 def _bench_engine(spec, seed=7):
     import tempfile
     mc = synth.bench_model_case(seed, spec)

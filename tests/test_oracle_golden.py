@@ -50,3 +50,12 @@ def test_oracle_matches_live_reference_on_fresh_seeds(seed, tmp_path):
     from tools.fuzz_ref import mk
     from tools.compare_ref import compare
     assert compare(mk(seed), str(tmp_path), verbose=False)
+
+
+@pytest.mark.skipif(not os.path.exists(util.REF_FIGBIRD), reason="oracle/_ref not built (needs /root/reference)")
+@pytest.mark.parametrize("seed", [701])
+def test_oracle_matches_live_reference_in_the_134_400_bracket(seed, tmp_path):
+    """The 134-400 bracket (hundreds of candidate lengths per gap), which tools/fuzz_ref.mk leaves out for its CPU cost."""
+    from tools.fuzz_ref import mk_mid
+    from tools.compare_ref import compare
+    assert compare(mk_mid(seed), str(tmp_path), verbose=False)

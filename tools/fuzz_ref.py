@@ -36,6 +36,18 @@ def mk(seed):
                                partial_reads_in_unmapped=rnd.random() < 0.7, read_n_rate=rnd.choice([0, 0, 0.01]),
                                script_itr=rnd.choice([1, 2]))
 
+def mk_mid(seed):
+    """Unmapped cases of the 134-400 bracket (candidate range [0.5 G0, 2.5 G0], Figbird.cpp:6894-6901; large_gap_flag off, up
+    to ~400 candidate lengths per gap), which mk() leaves out for its CPU cost: one gap, few reads."""
+    rnd = random.Random(seed)
+    L = rnd.choice([36, 50])
+    g = rnd.choice([134, 150, 180, 230, 300, 400])
+    return synth.make_case(f"fzm{seed}", seed, "unmapped", [(1500, g)], contig_len=1500 + g + 1500, read_len=L,
+                           insert_mean=rnd.choice([400, 600]), insert_sd=rnd.choice([20, 40]), coverage=rnd.choice([3, 5]),
+                           err=rnd.choice([0.0, 0.01]), n_model_pairs=1200, partial_reads_in_unmapped=rnd.random() < 0.7,
+                           read_n_rate=rnd.choice([0, 0.01]), script_itr=1)
+
+
 def one(seed):
     base = tempfile.mkdtemp(prefix=f"figfz{seed}_")
     try:
