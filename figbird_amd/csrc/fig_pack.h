@@ -170,7 +170,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         K.capC = std::max(K.capC, range);
         K.capG = std::max(K.capG, d.alloc_arg);
         double L = m->max_read_length;
-        if (m->unmapped_flag) cost[g] = (double)d.nU * std::min<double>(d.alloc_arg + L, 2200.0) * L * (d.lgf ? 2.0 : range * (d.G0 <= m->unm_limit / 3 ? 10.5 : 8.7));      // placeReads calls: measured medians (tools/cost_model_check.py)
+        if (m->unmapped_flag) cost[g] = (double)d.nU * std::min<double>(d.alloc_arg + L, 2200.0) * L * (d.lgf ? 2.0 : range * (d.G0 <= m->unm_limit / 3 ? 10.5 : 11.5));      // placeReads calls: measured medians (tools/cost_model_check.py)
         else cost[g] = (double)d.nP * L * L * range * 3.0;
         if (d.fillflag == -1) cost[g] = 1;
     }

@@ -863,8 +863,9 @@ std::vector<double> estimate_cost(const Batch &b, const RunArgs &a, int L) {
         if (a.unmapped == 1) {
             const double R = (double)(b.u_read_off[g + 1] - b.u_read_off[g]);
             const double cand = G <= a.unm_limit / 3 ? 3.0 * a.partial_len - 0.3 * G : (G <= a.unm_limit ? 2.0 * G : 1.0);
-            const double its = G <= a.unm_limit / 3 ? 10.5 : (G <= a.unm_limit ? 8.7 : 2.0);      // placeReads calls per candidate (tools/cost_model_check.py)
-            const double W = std::min(G * (G <= a.unm_limit ? 1.5 : 1.0) + L, 2200.0);
+            const double its = G <= a.unm_limit / 3 ? 10.5 : (G <= a.unm_limit ? 11.5 : 2.0);      // placeReads calls per candidate (tools/cost_model_check.py)
+            const double Gc = G <= a.unm_limit / 3 ? 0.5 * (0.3 * G + 3.0 * a.partial_len) : (G <= a.unm_limit ? 1.5 * G : G);   // typical candidate length
+            const double W = std::min(Gc + L, 2200.0);
             c[g] = R * W * L * std::max(cand, 1.0) * its + 1.0;
         } else {
             const double R = (double)(b.p_read_off[g + 1] - b.p_read_off[g]);

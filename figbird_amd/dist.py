@@ -30,9 +30,11 @@ def estimate_cost(gap_len: np.ndarray, n_reads: np.ndarray, read_len: int, unmap
     R = np.asarray(n_reads, dtype=np.float64)
     if unmapped:
         cand = np.where(G <= unm_limit // 3, 3.0 * partial_len - 0.3 * G, np.where(G <= unm_limit, 2.0 * G, 1.0))
-        # placeReads calls per candidate, calibrated on the bench batch (tools/cost_model_check.py, profiles/round2/cost_model_check_*.json)
-        its = np.where(G <= unm_limit // 3, 10.5, np.where(G <= unm_limit, 8.7, 2.0))
-        W = np.minimum(G * np.where(G <= unm_limit, 1.5, 1.0) + read_len, 2200.0)
+        # placeReads calls per candidate and the typical candidate length of the bracket, calibrated on the bench batch
+        # (tools/cost_model_check.py: profiles/round2/cost_model_check_before.json -> profiles/round3/cost_model_check_after.json)
+        its = np.where(G <= unm_limit // 3, 10.5, np.where(G <= unm_limit, 11.5, 2.0))
+        Gc = np.where(G <= unm_limit // 3, 0.5 * (0.3 * G + 3.0 * partial_len), np.where(G <= unm_limit, 1.5 * G, G))
+        W = np.minimum(Gc + read_len, 2200.0)
     else:
         cand = np.where(G <= partial_len, 3.0 * partial_len, np.where(G <= 2 * partial_len, 5.0 * G, 1.0))
         its = 3.0
