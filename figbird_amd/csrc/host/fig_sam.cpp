@@ -167,7 +167,10 @@ bool dup_jump(State &S, const std::string &read, int g) {      // check_duplicat
     if (S.jump_set[g].count(read)) return true;
     if (S.read_count[g] == 0) return false;
     const std::string core = read.size() >= 4 ? read.substr(2, read.size() - 4) : std::string();       // clip 2 from either end
-    for (const std::string &s1 : S.jump_reads[g]) if (s1.find(core) != std::string::npos) return true;
+    // (memmem: glibc's vectorised two-way search; this scan over every read already kept for the gap is the reference's own
+    //  quadratic duplicate test and dominates the ingest at thousands of reads per gap)
+    if (core.empty()) return !S.jump_reads[g].empty();
+    for (const std::string &s1 : S.jump_reads[g]) if (s1.size() >= core.size() && memmem(s1.data(), s1.size(), core.data(), core.size())) return true;
     return false;
 }
 
