@@ -27,6 +27,17 @@ def test_figfill_on_gpu_matches_reference_outputs(name, tmp_path):
         assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
 
 
+@pytest.mark.parametrize("name", ["unmapped_small", "unmapped_mid_err", "bench_b25", "bench_c1100"])
+def test_pair_chain_estep_still_matches_reference_outputs(name, tmp_path):
+    """FIG_ESTEP=pair: the pair-chain E-step (fig_hot_estep) everywhere -- the form the 1217-1600-column class, candidates over
+    875 bp and clipped gaps still take -- on fixtures the default build fills through the shared-factor form: same bytes."""
+    root = util.extract_golden(name, str(tmp_path))
+    r = util.run([util.FIGFILL] + util.meta(root)["fillgaps_argv"], root, {"FIG_ESTEP": "pair"})
+    assert r.returncode == 0, r.stderr
+    for fn in util.ref_files(root):
+        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+
+
 def _model_for(root):
     a = util.meta(root)["fillgaps_argv"]
     return api.model_from_files(os.path.join(root, "scf.fa"), os.path.join(root, "tmp") + "/", os.path.join(root, "tmp", "myout.sam"),
