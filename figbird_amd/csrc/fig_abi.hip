@@ -592,6 +592,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
     const int minc = getenv("FIG_MIN_CHUNK") ? std::max(1, atoi(getenv("FIG_MIN_CHUNK"))) : 16;      // candidates per gap and round, at least
     const double ipw_base = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_start = now();
     double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0, n_active_max = 0;
     while (true) {
         if ((e = hipMemcpyAsync(ctl, db.gapctl, ctl_n * 4, hipMemcpyDeviceToHost, stream)) != hipSuccess) return fail(e);
@@ -664,6 +665,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
         if ((e = launch_any(ctx, c, db, stream, 3, std::min(capacity, (int)endlist.size()), ln.d_items, (int)endlist.size(), ln.qsel)) != hipSuccess) return fail(e);
         ln.qsel ^= 1;
         nl++;
+        if (log) { const double t0 = now(); hipStreamSynchronize(stream); fprintf(stderr, "[figsched] capG=%d end kernel: %d gaps, %.1f ms (lane done at %.1f ms since its first round)\n", c.c.capG, (int)endlist.size(), now() - t0, now() - t_start); }
     }
     (void)n_cls;
     return nl;
