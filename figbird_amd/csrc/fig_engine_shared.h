@@ -155,6 +155,16 @@ FIG_FI void fig_sh_chain(double (&p)[FIG_SH_C], const FigPQ *colp, int ncolE, fi
 #pragma unroll
     for (int b = 0; b < 4; b++) a0[b] = colp[b * ncolE];
     int j = 0;
+#ifndef FIG_SH_UNROLL
+#define FIG_SH_UNROLL 2          // step pairs per loop trip
+#endif
+    for (; j + 2 * FIG_SH_UNROLL <= L; j += 2 * FIG_SH_UNROLL) {
+#pragma unroll
+        for (int u = 0; u < FIG_SH_UNROLL; u++) {
+            fig_sh_step<NS>(p, w0, k0, a0, w1, k1, a1, colp, ncolE, st, ktf, ktr, j + 2 * u + 1);
+            fig_sh_step<NS>(p, w1, k1, a1, w0, k0, a0, colp, ncolE, st, ktf, ktr, j + 2 * u + 2);
+        }
+    }
     for (; j + 2 <= L; j += 2) {
         fig_sh_step<NS>(p, w0, k0, a0, w1, k1, a1, colp, ncolE, st, ktf, ktr, j + 1);
         fig_sh_step<NS>(p, w1, k1, a1, w0, k0, a0, colp, ncolE, st, ktf, ktr, j + 2);
