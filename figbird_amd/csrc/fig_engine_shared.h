@@ -296,8 +296,8 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
         for (int q0 = 0; q0 < nrd; q0 += NR) {
             const unsigned irr = (unsigned)fig_u((int)S.sh_irr[q0 >> 5]) >> (q0 & 31);      // bits 0..NR-1: the group's reads
             // the group's scalars, all four rows at once (lane t of every wave reads row t's, v_readlane hands them round)
-            int g_lo = 0, g_hi = -1, g_len = 0;
-            if (lane < NR && c0 + q0 + lane < nU) { g_lo = S.sh_lo[q0 + lane]; g_hi = S.sh_hi[q0 + lane]; g_len = S.sh_len[q0 + lane]; }
+            int g_lo = 0, g_hi = -1;
+            if (lane < NR && c0 + q0 + lane < nU) { g_lo = S.sh_lo[q0 + lane]; g_hi = S.sh_hi[q0 + lane]; }
             if (wave < NR) {
                 plb[wave * 64 + lane] = plv_next;              // fetched while the previous group ran
                 plv_next = 0;
@@ -308,12 +308,12 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                     if (lane < ndw) plv_next = U.packed[wbase + fig_u((int)S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
                 }
             }
-            if (tid < NR) { S.tm_lo[tid] = g_lo; S.tm_hi[tid] = g_hi; S.tm_len[tid] = g_len; }
             double pc[NR][KP];
 #pragma unroll
             for (int t = 0; t < NR; t++)
 #pragma unroll
                 for (int k = 0; k < KP; k++) pc[t][k] = pn[t][k];
+            FIG_TICK(E, 19);
 #pragma unroll
             for (int t = 0; t < NR; t++) {
                 const int s = q0 + t, r = c0 + s;
@@ -341,6 +341,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                             }
                         }
                     }
+                    FIG_TICK(E, 20);
                     long long bits; memcpy(&bits, &pr, 8);
                     const unsigned hi32 = (unsigned)((unsigned long long)bits >> 32), lo32 = (unsigned)((unsigned long long)bits & 0xffffffffULL);
                     const unsigned mh = fig_wave_max_u32(hi32);
@@ -355,6 +356,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                         double mv; memcpy(&mv, &mb, 8);
                         S.wv_v[t * 8 + wave] = any ? mv : 0.0; S.wv_o[t * 8 + wave] = ao;
                     }
+                    FIG_TICK(E, 21);
                 } else {
                     // generic chain (N bases / short read): all lanes over the read's window, zero outside it
                     FigReadS rs; rs.len = fig_u(S.sh_len[s]); rs.rev = fig_u(S.sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = wbase + fig_u((int)S.sh_woff[s]);
@@ -395,21 +397,23 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
             if (tid >= 64 && tid < 64 + NR) {
                 const int t = tid - 64, s = q0 + t;
                 if (c0 + s < nU) {
-                    const bool isirr = (irr >> t) & 1u;
                     FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
                     if (S.sh_hi[s] >= S.sh_lo[s]) for (int k = 0; k < nw; k++) { FigBest y; y.v = S.wv_v[t * 8 + k]; y.o = S.wv_o[t * 8 + k]; b = fig_best_merge(b, y); }
-                    if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + s] = isirr ? b.v : fig_log10(b.v);
+                    if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + s] = b.v;   // (regular reads: the product; its log10 is taken per super-chunk below)
                     else { E.scr.maxlv[c0 + s] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
                     E.scr.hint_e[c0 + s] = b.o;
                 }
             }
+            FIG_TICK(E, 27);
             // ---- column pass over the group's rows (as fig_hot_estep: base-owning waves, register accumulators)
+            uint32_t plv_nx = plb[lane];                       // row 0's position lists; row t + 1's are fetched behind row t's additions
             for (int t = 0; t < NR && c0 + q0 + t < nU; t++) {
                 if (U.nw == 8) { if ((t + (wave >> 2)) & 1) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
-                const int lo = fig_u(S.tm_lo[t]), hi = fig_u(S.tm_hi[t]);
+                const uint32_t plv = plv_nx;
+                if (t + 1 < NR) plv_nx = plb[(t + 1) * 64 + lane];
+                const int lo = __builtin_amdgcn_readlane(g_lo, t), hi = __builtin_amdgcn_readlane(g_hi, t);
                 if (hi < lo) continue;
                 const double *wrow = W + (long long)t * Wcap + (U.L - 1);
-                const uint32_t plv = plb[t * 64 + lane];
                 const uint32_t cw0 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 0), cw1 = (uint32_t)__builtin_amdgcn_readlane((int)plv, 1);
                 const int nA = (int)(cw0 & 255), nC = (int)((cw0 >> 8) & 255), nG = (int)((cw0 >> 16) & 255), nT_ = (int)(cw0 >> 24);
                 const int n4 = (int)(cw1 & 255);
@@ -418,6 +422,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 const int d0 = pb_c == 0 ? 2 : pb_c == 1 ? dC : pb_c == 2 ? dG : dT;
                 const double *wl = wrow + pb_x0;
                 int k4 = 0;
+                FIG_TICK(E, 28); FIG_COUNT(E, 31, 1); FIG_COUNT(E, 32, n * CPL);
                 for (; k4 + 1 <= (n >> 2); k4++) {
                     const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
                     const double *p0 = wl - (int)(s4 & 255), *p1 = wl - (int)((s4 >> 8) & 255), *p2 = wl - (int)((s4 >> 16) & 255), *p3 = wl - (int)(s4 >> 24);
@@ -447,12 +452,24 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                         for (int i = 0; i < CPL; i++) acc[i] += w1[i];
                     }
                 }
+                FIG_TICK(E, 29);
                 if (n & 3) {
-                    uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
-                    for (int qq = 0; qq < (n & 3); qq++, s4 >>= 8) {
-                        const double *p0 = wl - (int)(s4 & 255);
+                    // the last one to three positions: their loads go out together (the list's padding bytes are 0, a valid offset)
+                    const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, d0 + k4);
+                    const int rem = n & 3;
+                    const double *p0 = wl - (int)(s4 & 255), *p1 = wl - (int)((s4 >> 8) & 255), *p2 = wl - (int)((s4 >> 16) & 255);
+                    double w0[CPL], w1[CPL], w2[CPL];
 #pragma unroll
-                        for (int i = 0; i < CPL; i++) acc[i] += FIG_LDV(p0 + i * 64);
+                    for (int i = 0; i < CPL; i++) { w0[i] = FIG_LDV(p0 + i * 64); w1[i] = FIG_LDV(p1 + i * 64); w2[i] = FIG_LDV(p2 + i * 64); }
+#pragma unroll
+                    for (int i = 0; i < CPL; i++) acc[i] += w0[i];
+                    if (rem > 1) {
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w1[i];
+                    }
+                    if (rem > 2) {
+#pragma unroll
+                        for (int i = 0; i < CPL; i++) acc[i] += w2[i];
                     }
                 }
                 if (n4 > 0) {
@@ -465,11 +482,17 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                         E.scr.cnt[4 * cg + x] = a;
                     }
                 }
+                FIG_TICK(E, 30);
             }
             if (U.nw == 8) __builtin_amdgcn_s_setprio(0);
             FIG_TICK(E, 38);
             FIG_SYNC();
             FIG_TICK(E, 39);
+        }
+        // maxlv of the super-chunk's regular reads: log10 of the maximal product, one read per thread
+        if (tid < nrd) {
+            const bool isirr = (S.sh_irr[tid >> 5] >> (tid & 31)) & 1u;
+            if (!isirr && E.scr.hint_e[c0 + tid] != FIG_NOPOS) E.scr.maxlv[c0 + tid] = fig_log10(E.scr.maxlv[c0 + tid]);
         }
     }
 #pragma unroll
