@@ -5,6 +5,8 @@
 //   V1: the same with two register sets (loads of group k + 1 issued before the adds of group k)
 //   V2: 8 positions per group (CPL <= 2)
 //   V3: loads only (no adds): what the LDS delivers to this access pattern at this occupancy
+//   V4: two register sets of 8 loads with hand-placed waits (inline-asm ds_read_b64, s_waitcnt lgkmcnt(8)): the compiler's own
+//       waits in V1/V2 are lgkmcnt(0) at the loop's join points, which undoes the overlap
 // and for 1 and 2 workgroups per CU.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -52,6 +54,36 @@ __global__ void __launch_bounds__(256) k(double *out, unsigned long long *cyc, i
                     for (int i = 0; i < CPL; i++) asm volatile("" :: "v"(w0[i]), "v"(w1[i]), "v"(w2[i]), "v"(w3[i]));
                 }
             }
+        } else if (V == 4) {
+            constexpr int GP = 8 / CPL;                         // positions per set of 8 loads
+            const int ns = n / GP;
+            const unsigned wlb = (unsigned)(uintptr_t)(const __attribute__((address_space(3))) double *)wl;
+            double wa[8], wb[8];
+            auto ld = [&](double (&w)[8], int g) {
+#pragma unroll
+                for (int q = 0; q < GP; q++) {
+                    const int pi = g * GP + q;
+                    const uint32_t s4 = (uint32_t)__builtin_amdgcn_readlane((int)plv, pi >> 2);
+                    const unsigned a = wlb - 8u * ((s4 >> (8 * (pi & 3))) & 255u);
+#pragma unroll
+                    for (int i = 0; i < CPL; i++) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(w[q * CPL + i]) : "v"(a), "n"(512 * i));
+                }
+            };
+            auto ad = [&](double (&w)[8]) {
+#pragma unroll
+                for (int q = 0; q < GP; q++)
+#pragma unroll
+                    for (int i = 0; i < CPL; i++) acc[i] += w[q * CPL + i];
+            };
+#define WAIT(w, N) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(w[0]), "+v"(w[1]), "+v"(w[2]), "+v"(w[3]), "+v"(w[4]), "+v"(w[5]), "+v"(w[6]), "+v"(w[7]))
+            if (ns > 0) ld(wa, 0);
+            int g = 0;
+            for (; g + 2 < ns; g += 2) {
+                ld(wb, g + 1); WAIT(wa, 8); ad(wa);
+                ld(wa, g + 2); WAIT(wb, 8); ad(wb);
+            }
+            if (g + 1 < ns) { ld(wb, g + 1); WAIT(wa, 8); ad(wa); WAIT(wb, 0); ad(wb); }
+            else if (g < ns) { WAIT(wa, 0); ad(wa); }
         } else {
             constexpr int GP = V == 2 ? 8 : 4;
             const int ngp = n / GP;
@@ -104,7 +136,8 @@ template <int CPL, int V> void run(double *d, unsigned long long *dc, int per_cu
         hipEventElapsedTime(&ms, e0, e1);
         hipMemcpy(&c, dc, 8, hipMemcpyDeviceToHost);
     }
-    const double la = (double)rows * (n / (V == 2 ? 8 : 4)) * (V == 2 ? 8 : 4) * CPL;       // load+adds per wave
+    const int gp = V == 2 ? 8 : V == 4 ? 8 / CPL : 4;
+    const double la = (double)rows * (n / gp) * gp * CPL;       // load+adds per wave
     const double waves = nblk * 4.0;
     printf("%-28s CPL=%d %d WG/CU: %7.2f ms, %6.2f wave-cycles per load+add, %6.2f CU-cycles per wave-load (LDS array: 2)\n", name, CPL, per_cu, ms,
            (double)c / waves / la, ms * 1e-3 * 2.4e9 / (la * 4.0 * per_cu));
@@ -117,13 +150,16 @@ int main() {
         run<4, 0>(d, dc, per_cu, "V0 engine loop");
         run<4, 1>(d, dc, per_cu, "V1 two register sets");
         run<4, 3>(d, dc, per_cu, "V3 loads only");
+        run<4, 4>(d, dc, per_cu, "V4 two sets, manual waits");
         run<2, 0>(d, dc, per_cu, "V0 engine loop");
         run<2, 1>(d, dc, per_cu, "V1 two register sets");
         run<2, 2>(d, dc, per_cu, "V2 8 positions, two sets");
         run<2, 3>(d, dc, per_cu, "V3 loads only");
+        run<2, 4>(d, dc, per_cu, "V4 two sets, manual waits");
         run<1, 0>(d, dc, per_cu, "V0 engine loop");
         run<1, 2>(d, dc, per_cu, "V2 8 positions, two sets");
         run<1, 3>(d, dc, per_cu, "V3 loads only");
+        run<1, 4>(d, dc, per_cu, "V4 two sets, manual waits");
     }
     return 0;
 }
