@@ -177,6 +177,10 @@ template <int NS>
 FIG_FI void fig_sh_step(double (&p)[FIG_SH_C], const uint32_t (&wc)[NS / 2], const double (&kc)[4], const FigPQ (&ac)[4],
                         uint32_t (&wn)[NS / 2], double (&kn)[4], FigPQ (&an)[4], const FigPQ *colp, int ncolE, fig_cu32p st, fig_cdp ktf, fig_cdp ktr, int jn) {
     {
+        // The current step's scalar loads (stream row, {1-e, e} pairs) had a whole step to arrive: wait for them BEFORE the next
+        // step's loads go out.  Scalar loads return out of order, so the only wait that covers them is lgkmcnt(0), and placed
+        // at their first use (where the compiler puts it) it would also drain the four ds_read_b128 just issued for the next step.
+        __builtin_amdgcn_s_waitcnt(0xc07f);                    // lgkmcnt(0), vmcnt / expcnt untouched
         fig_cu32p sn = st + jn * (FIG_SH_C / 2);
 #pragma unroll
         for (int k = 0; k < NS / 2; k++) wn[k] = sn[k];
@@ -185,12 +189,15 @@ FIG_FI void fig_sh_step(double (&p)[FIG_SH_C], const uint32_t (&wc)[NS / 2], con
 #pragma unroll
         for (int b = 0; b < 4; b++) an[b] = cn[b * ncolE];
     }
-    double f[8];
+    // f[b] = P (1 - e[j]) + e[j] Q for forward reads (:3581-3589), f[4 + b] with {1 - e[L-1-j], e[L-1-j]} for reverse reads
+    // (:3569-3576); the sixteen products first and the eight sums after them, so that no sum waits for its own products
+    double f[8], m1[8], m2[8];
 #pragma unroll
-    for (int b = 0; b < 4; b++) {
-        f[b] = ac[b].p * kc[0] + kc[1] * ac[b].q;           // forward reads: {1-e[j], e[j]}          (:3581-3589)
-        f[4 + b] = ac[b].p * kc[2] + kc[3] * ac[b].q;       // reverse reads: {1-e[L-1-j], e[L-1-j]}  (:3569-3576)
-    }
+    for (int b = 0; b < 4; b++) { m1[b] = ac[b].p * kc[0]; m1[4 + b] = ac[b].p * kc[2]; }
+#pragma unroll
+    for (int b = 0; b < 4; b++) { m2[b] = kc[1] * ac[b].q; m2[4 + b] = kc[3] * ac[b].q; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) f[i] = m1[i] + m2[i];
     const double one = 1.0;
     if (NS == 32) { fig_sh_mul16(&p[0], f, one, &wc[0]); fig_sh_mul16(&p[16], f, one, &wc[8]); }
     else if (NS == 16) fig_sh_mul16(&p[0], f, one, &wc[0]);
