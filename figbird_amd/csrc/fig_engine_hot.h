@@ -1114,13 +1114,20 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 const uint32_t rw0 = sw ? pkl[0] : 0u, rw1 = sw ? pkl[1] : 0u;
                 const int Wn = sw ? w.hi - w.lo + 1 : 0;
                 const FigU4 *cwx = cwn + xoff;
-                for (int i = 0; fig_wave_any(i < Wn); i++) {
-                    if (i >= Wn) continue;
+                // four placements per trip: their records are fetched together (one LDS round trip per four tests instead of one per
+                // test; a lane past its window re-reads its last record and fails the `i < Wn` test), judged in placement order
+                for (int i0 = 0; fig_wave_any(i0 < Wn); i0 += 4) {
+                  FigU4 rec4[4];
+#pragma unroll
+                  for (int u = 0; u < 4; u++) { const int iu = i0 + u < Wn ? i0 + u : (Wn > 0 ? Wn - 1 : 0); rec4[u] = cwx[w.lo + iu]; }
+#pragma unroll
+                  for (int u = 0; u < 4; u++) {
+                    const int i = i0 + u;
                     const int o = w.lo + i;
-                    const FigU4 rec = cwx[o];
+                    const FigU4 rec = rec4[u];
                     const uint32_t d0 = rec.x ^ rw0, d1 = rec.y ^ rw1;
                     const int mm = __builtin_popcount(((d0 | (d0 >> 1)) | rec.z) & 0x55555555u) + __builtin_popcount(((d1 | (d1 >> 1)) | rec.w) & 0x55555555u);
-                    if (mm < mcut && o != h1 && o != h2) {
+                    if (i < Wn && mm < mcut && o != h1 && o != h2) {
                         int mmf = 0;                                  // whole-read count, 32 bases per record
                         for (int k = 0; 32 * k < Lfull; k++) {
                             const FigU4 rk = cwx[o + 32 * k];
@@ -1132,6 +1139,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                         }
                         if (mmf < mcut) { if (c1 == FIG_NOPOS) c1 = o; else if (c2 == FIG_NOPOS) c2 = o; else ovf = true; }
                     }
+                  }
                 }
             }
             if (part) {
