@@ -1085,6 +1085,30 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                         const uint32_t wd = ev ? pkl[wi] : 0u;
                         const int j0 = wi * 16;
                         int nb = Lfull - j0; if (nb > 16) nb = 16;
+                        if (nb == 16) {
+                            // a full word of the read: eight columns' entries fetched together, then multiplied in in order
+                            // (same operations, same order: the loop below with its loads hoisted)
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                double ca8[8], cb8[8];
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    const int jj = 8 * h + u, j = j0 + jj;
+                                    const int b = (int)((wd >> (2 * jj)) & 3);
+                                    ca8[u] = C[b * ncolE + xa + j];
+                                    cb8[u] = two ? C[b * ncolE + xb + j] : 0.0;
+                                }
+#pragma unroll
+                                for (int u = 0; u < 8; u++) {
+                                    const int j = j0 + 8 * h + u;
+                                    const double m3 = rev ? mtr[2 * j] : mtf[2 * j], e = rev ? mtr[2 * j + 1] : mtf[2 * j + 1];
+                                    const double fa = e * ca8[u];
+                                    qa *= (ca8[u] < 0 ? m3 : fa);
+                                    if (two) { const double fb = e * cb8[u]; qb *= (cb8[u] < 0 ? m3 : fb); }
+                                }
+                            }
+                            continue;
+                        }
                         for (int jj = 0; jj < nb; jj++) {
                             const int j = j0 + jj;
                             const int b = (int)((wd >> (2 * jj)) & 3);
