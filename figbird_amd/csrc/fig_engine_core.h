@@ -438,10 +438,18 @@ FIG_D void fig_detect_overlap(FigEng &E, const int *pflag, int stride, int gaple
 }
 
 // findOverlapUnmapped, Figbird.cpp:2945-3019.  Lane 0.
+// Where the lane-0 sorts of the post-processing keep their (pos, len, index) triples: the weight rows in LDS when they hold them
+// (the rows are idle outside the E-step; a one-lane introsort makes ~n log n dependent accesses, and an LDS round trip is a
+// fifth of one to the scratch slab), else the slab.
+FIG_D FigTrip *fig_sort_buf(FigEng &E, int n) {
+    if (E.w_lds && (long long)n * (long long)sizeof(FigTrip) <= (long long)E.nteams * (long long)E.Wcap * 8LL) return (FigTrip *)E.wbuf;
+    return E.scr.sortbuf;
+}
+
 FIG_D double fig_find_overlap_unmapped(FigEng &E) {
     FigState &S = *E.S;
     int n = E.g->nU;
-    FigTrip *vec = E.scr.sortbuf;
+    FigTrip *vec = fig_sort_buf(E, n);
     for (int i = 0; i < n; i++) {
         vec[i].v[0] = E.scr.frp[i * 2]; vec[i].v[1] = E.scr.frp[i * 2 + 1];
         vec[i].v[2] = i;
@@ -909,7 +917,7 @@ FIG_D int fig_recheck_sequence(FigEng &E, const int *pos) {
     int *region = E.scr.region;
     int region_count = fig_find_region(E, region);
     int len = S.G, n = E.g->nU, G0 = E.g->G0;
-    FigTrip *vec = E.scr.sortbuf;
+    FigTrip *vec = fig_sort_buf(E, n);
     for (int i = 0; i < n; i++) { vec[i].v[0] = pos[i * 2]; vec[i].v[1] = pos[i * 2 + 1]; vec[i].v[2] = i; }
     fig_std_sort(vec, n);
     int flag = 0;
