@@ -137,6 +137,16 @@ FIG_FI void fig_weights_n(const double (&x)[N], double (&w)[N]) {
     }
 }
 
+// Global (address space 1) views of the slab and batch arrays the E-step touches.  fig_uptr() hands out generic pointers, and a
+// generic access is a FLAT instruction: it counts on lgkmcnt as well as vmcnt and returns out of order with LDS operations, so
+// with one in flight every LDS wait becomes lgkmcnt(0) and also waits for the L2 round trip of the product rows.  global_load /
+// global_store count on vmcnt alone.
+typedef double __attribute__((address_space(1))) *fig_gdp;
+typedef const double __attribute__((address_space(1))) *fig_gcdp;
+typedef const uint32_t __attribute__((address_space(1))) *fig_gcu32p;
+// FigState lives in LDS; through E.S (a generic pointer) its fields are FLAT loads too: the staging arrays go through this view
+typedef FigState __attribute__((address_space(3))) *fig_lsp;
+
 // ---- the indexed multiplies.  F0..F7 and the constant 1.0 are pinned to v[232:249]; p* are the products (any registers);
 // w* hold two 16-bit entries of the operand-select stream each: the value M0 takes (0x1000 = "SRC0 is indexed" | register
 // offset 2 * (4 * reverse + base), or 16 = the 1.0 for a slot without a regular read).  Per multiply ONE SALU instruction.
@@ -243,19 +253,20 @@ FIG_FI void fig_sh_chain(double (&p)[FIG_SH_C], const FigPQ *colp, int ncolE, fi
 // scratch slab, prow[s * pst + (o + L - 1)] (coalesced 512-byte stores; read back four reads at a time by phase B).
 // Lanes past the last placement (vo false) run on the tile's first placement and store nothing.
 template <int NS>
-FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ *PQ, fig_cu32p stream, double *prow, const int pst, const int o, const bool vo, const int ocalc) {
+FIG_FI void fig_sh_unit(const int s0, FigState &S, const FigHotU &U, const FigPQ *PQ, fig_cu32p stream, fig_gdp prow, const int pst, const int o, const bool vo, const int ocalc) {
     // s0 = first read of the unit, counted from the super-chunk's first read (S.sh_* / prow row index); `stream` = its chunk's rows
+    const fig_lsp SL = (fig_lsp)&S;
     double p[FIG_SH_C];
 #pragma unroll
     for (int i = 0; i < NS; i++) {
         const int s = s0 + i;
-        const int lo = fig_u(S.sh_lo[s]), hi = fig_u(S.sh_hi[s]), tis0 = fig_u(S.sh_tis0[s]), dir = (fig_u(S.sh_aux[s]) & 4) ? 1 : -1;
+        const int lo = fig_u(SL->sh_lo[s]), hi = fig_u(SL->sh_hi[s]), tis0 = fig_u(SL->sh_tis0[s]), dir = (fig_u(SL->sh_aux[s]) & 4) ? 1 : -1;
         p[i] = 1.0;
-        if (ocalc >= lo && ocalc <= hi) p[i] = U.insd[tis0 + dir * ocalc];
+        if (ocalc >= lo && ocalc <= hi) p[i] = ((fig_gcdp)U.insd)[tis0 + dir * ocalc];
     }
     fig_sh_chain<NS>(p, PQ + (ocalc + U.xoff), U.ncolE, stream + ((s0 & (FIG_SH_C - 1)) >> 1), (fig_cdp)U.kt_fwd, (fig_cdp)U.kt_rev, U.L);
     if (vo) {
-        double *dst = prow + (long long)s0 * pst + (o + U.L - 1);
+        fig_gdp dst = prow + (long long)s0 * pst + (o + U.L - 1);
 #pragma unroll
         for (int i = 0; i < NS; i++) dst[(long long)i * pst] = p[i];
     }
@@ -268,6 +279,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
     constexpr int NR = 4;                                      // weight rows per group of the column pass (the class has >= 4)
     constexpr int KP = 2;                                      // placements per thread and row in phase B: Wn <= KP * nt (dispatcher)
     FigState &S = *E.S;
+    const fig_lsp SL = (fig_lsp)E.S;
     const FigHotU U = fig_hot_uniforms(E);
     const int G = U.G, nU = U.nU, cg = U.cg;
     const long long ub = U.ub;
@@ -277,7 +289,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
     const int wave = fig_u(E.wave), lane = E.lane, tid = E.tid, nw = U.nw;
     const fig_cu32p stream0 = (fig_cu32p)(fig_uptr(fig_uptr(E.B)->ustream) + fig_u64(fig_uptr(E.g)->streamOff));
     const long long wbase = nU > 0 ? fig_u64(U.u_woff[ub]) : 0;     // packed-read offsets are kept relative to the gap's first read
-    double *prow = fig_uptr(E.scr.wg);                        // raw products of the chunk: [32 reads][pst] (scratch slab, L2)
+    const fig_gdp prow = (fig_gdp)fig_uptr(E.scr.wg);                        // raw products of the chunk: [32 reads][pst] (scratch slab, L2)
     const int pst = Wcap;
     double acc[CPL];
 #pragma unroll
@@ -307,18 +319,18 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 lo = w.lo; hi = w.hi; tis0 = w.tis0; dir = w.dir;
                 irr = ((aux >> 1) & 1) != 0 || len != U.L;
             }
-            S.sh_lo[tid] = (short)lo; S.sh_hi[tid] = (short)hi; S.sh_tis0[tid] = tis0; S.sh_len[tid] = (unsigned char)len;
-            S.sh_aux[tid] = (unsigned char)((aux & 3) | (dir > 0 ? 4 : 0)); S.sh_woff[tid] = (unsigned)(woff - wbase);
+            SL->sh_lo[tid] = (short)lo; SL->sh_hi[tid] = (short)hi; SL->sh_tis0[tid] = tis0; SL->sh_len[tid] = (unsigned char)len;
+            SL->sh_aux[tid] = (unsigned char)((aux & 3) | (dir > 0 ? 4 : 0)); SL->sh_woff[tid] = (unsigned)(woff - wbase);
             const unsigned long long im = fig_ballot(irr);
-            if (lane == 0) { S.sh_irr[2 * wave] = (unsigned)(im & 0xffffffffULL); S.sh_irr[2 * wave + 1] = (unsigned)(im >> 32); }
+            if (lane == 0) { SL->sh_irr[2 * wave] = (unsigned)(im & 0xffffffffULL); SL->sh_irr[2 * wave + 1] = (unsigned)(im >> 32); }
         }
         FIG_SYNC();
         // position lists of the first row group: fetched now, parked in plb when the group starts (wave t: row t)
         uint32_t plv_next = 0;
         if (wave < NR && c0 + wave < nU) {
-            const int len = fig_u(S.sh_len[wave]);
+            const int len = fig_u(SL->sh_len[wave]);
             const int ndw = 2 + ((len + 3) >> 2) + 4;
-            if (lane < ndw) plv_next = U.packed[wbase + fig_u((int)S.sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+            if (lane < ndw) plv_next = ((fig_gcu32p)U.packed)[wbase + fig_u((int)SL->sh_woff[wave]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
         }
         FIG_TICK(E, 34);
         // ---- phase A: lanes = placements, the raw products of all reads -> prow.  Work items = (chunk, tile) pairs: full
@@ -360,18 +372,18 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
 #pragma unroll
             for (int k = 0; k < KP; k++) { const int i = tid + k * U.nt; pn[t][k] = (i < Wn && c0 + t < nU) ? prow[(long long)t * pst + i] : 0.0; }
         for (int q0 = 0; q0 < nrd; q0 += NR) {
-            const unsigned irr = (unsigned)fig_u((int)S.sh_irr[q0 >> 5]) >> (q0 & 31);      // bits 0..NR-1: the group's reads
+            const unsigned irr = (unsigned)fig_u((int)SL->sh_irr[q0 >> 5]) >> (q0 & 31);      // bits 0..NR-1: the group's reads
             // the group's scalars, all four rows at once (lane t of every wave reads row t's, v_readlane hands them round)
             int g_lo = 0, g_hi = -1;
-            if (lane < NR && c0 + q0 + lane < nU) { g_lo = S.sh_lo[q0 + lane]; g_hi = S.sh_hi[q0 + lane]; }
+            if (lane < NR && c0 + q0 + lane < nU) { g_lo = SL->sh_lo[q0 + lane]; g_hi = SL->sh_hi[q0 + lane]; }
             if (wave < NR) {
                 plb[wave * 64 + lane] = plv_next;              // fetched while the previous group ran
                 plv_next = 0;
                 const int sn = q0 + NR + wave;                 // the same row of the next group of this chunk
                 if (sn < nrd) {
-                    const int len = fig_u(S.sh_len[sn]);
+                    const int len = fig_u(SL->sh_len[sn]);
                     const int ndw = 2 + ((len + 3) >> 2) + 4;
-                    if (lane < ndw) plv_next = U.packed[wbase + fig_u((int)S.sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
+                    if (lane < ndw) plv_next = ((fig_gcu32p)U.packed)[wbase + fig_u((int)SL->sh_woff[sn]) + ((len + 15) >> 4) + ((len + 31) >> 5) + lane];
                 }
             }
             double pc[NR][KP];
@@ -436,17 +448,17 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                     if (lane == 0) {
                         const unsigned long long mb = ((unsigned long long)mh << 32) | ml;
                         double mv; memcpy(&mv, &mb, 8);
-                        S.wv_v[t * 8 + wave] = any ? mv : 0.0; S.wv_o[t * 8 + wave] = ao;
+                        SL->wv_v[t * 8 + wave] = any ? mv : 0.0; SL->wv_o[t * 8 + wave] = ao;
                     }
                     FIG_TICK(E, 21);
                 } else {
                     // generic chain (N bases / short read): all lanes over the read's window, zero outside it
-                    FigReadS rs; rs.len = fig_u(S.sh_len[s]); rs.rev = fig_u(S.sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = wbase + fig_u((int)S.sh_woff[s]);
+                    FigReadS rs; rs.len = fig_u(SL->sh_len[s]); rs.rev = fig_u(SL->sh_aux[s]) & 1; rs.hasN = 1; rs.pos = 0; rs.woff = wbase + fig_u((int)SL->sh_woff[s]);
                     fig_cu32p pk = (fig_cu32p)(U.packed + rs.woff);
                     const int nw2 = (rs.len + 15) >> 4;
                     fig_cdp kt = (fig_cdp)(rs.rev ? U.kt_rev + 2 * (U.L - rs.len) : U.kt_fwd);
                     const double *Q4 = fig_q4_ptr<LDS>(E);
-                    const int tis0 = fig_u(S.sh_tis0[s]), dir = (fig_u(S.sh_aux[s]) & 4) ? 1 : -1;
+                    const int tis0 = fig_u(SL->sh_tis0[s]), dir = (fig_u(SL->sh_aux[s]) & 4) ? 1 : -1;
                     for (int i = -(U.L - 1) + tid; i < G; i += U.nt) if (i < lo || i > hi) wrow[i] = 0.0;
                     FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
                     unsigned long long nplace = 0, nadd = 0;
@@ -461,7 +473,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                     const double bv = fig_wave_max_dpp(best.o == FIG_NOPOS ? -FIG_DBL_MAX : best.v);
                     const unsigned long long am = fig_ballot(best.o != FIG_NOPOS && best.v == bv);
                     const int ao = am ? fig_lane_read_i32(best.o, fig_ctz64(am)) : FIG_NOPOS;
-                    if (lane == 0) { S.wv_v[t * 8 + wave] = bv; S.wv_o[t * 8 + wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; }
+                    if (lane == 0) { SL->wv_v[t * 8 + wave] = bv; SL->wv_o[t * 8 + wave] = bv > -FIG_DBL_MAX ? ao : FIG_NOPOS; }
                 }
             }
             FIG_TICK(E, 36);
@@ -480,7 +492,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
                 const int t = tid - 64, s = q0 + t;
                 if (c0 + s < nU) {
                     FigBest b; b.v = -FIG_DBL_MAX; b.o = FIG_NOPOS;
-                    if (S.sh_hi[s] >= S.sh_lo[s]) for (int k = 0; k < nw; k++) { FigBest y; y.v = S.wv_v[t * 8 + k]; y.o = S.wv_o[t * 8 + k]; b = fig_best_merge(b, y); }
+                    if (SL->sh_hi[s] >= SL->sh_lo[s]) for (int k = 0; k < nw; k++) { FigBest y; y.v = SL->wv_v[t * 8 + k]; y.o = SL->wv_o[t * 8 + k]; b = fig_best_merge(b, y); }
                     if (b.o != FIG_NOPOS) E.scr.maxlv[c0 + s] = b.v;   // (regular reads: the product; its log10 is taken per super-chunk below)
                     else { E.scr.maxlv[c0 + s] = 0; fig_atomic_add_i32(&S.invalid_count, 1); }
                     E.scr.hint_e[c0 + s] = b.o;
@@ -573,7 +585,7 @@ FIG_NOINLINE FIG_D void fig_hot_estep_sh(FigEng &E, int gapoffset) {
         }
         // maxlv of the super-chunk's regular reads: log10 of the maximal product, one read per thread
         if (tid < nrd) {
-            const bool isirr = (S.sh_irr[tid >> 5] >> (tid & 31)) & 1u;
+            const bool isirr = (SL->sh_irr[tid >> 5] >> (tid & 31)) & 1u;
             if (!isirr && E.scr.hint_e[c0 + tid] != FIG_NOPOS) E.scr.maxlv[c0 + tid] = fig_log10(E.scr.maxlv[c0 + tid]);
         }
     }
