@@ -93,12 +93,21 @@ static double *fig_lds = nullptr;
 #define FIG_RFL(x) (x)
 typedef const uint32_t *fig_cu32p;
 typedef const double *fig_cdp;
+typedef double *fig_gdp;
+typedef const double *fig_gcdp;
+typedef const uint32_t *fig_gcu32p;
 #else
 extern __shared__ __attribute__((aligned(16))) double fig_lds[];
 #define FIG_RFL(x) __builtin_amdgcn_readfirstlane(x)
 // constant address space: uniform loads through these become scalar (s_load) instructions
 typedef const uint32_t __attribute__((address_space(4))) *fig_cu32p;
 typedef const double __attribute__((address_space(4))) *fig_cdp;
+// Global (address space 1) views of slab and batch arrays.  fig_uptr() hands out generic pointers, and a generic access is a FLAT
+// instruction: it counts on lgkmcnt as well as vmcnt and returns out of order with LDS operations, so with one in flight every LDS
+// wait becomes lgkmcnt(0) and also waits for the global round trip.  global_load / global_store count on vmcnt alone.
+typedef double __attribute__((address_space(1))) *fig_gdp;
+typedef const double __attribute__((address_space(1))) *fig_gcdp;
+typedef const uint32_t __attribute__((address_space(1))) *fig_gcu32p;
 #endif
 
 // 16-byte aligned so that the hot loop fetches a {P,Q} pair with ONE ds_read_b128 (256 B/clk/CU);

@@ -1053,7 +1053,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             const int r = r0 + E.tid;
             bool part = false;
             int h1 = FIG_NOPOS, h2 = FIG_NOPOS, rev = 0;
-            const uint32_t *pkl = U.packed;
+            fig_gcu32p pkl = (fig_gcu32p)U.packed;          // global view: a generic pointer's FLAT loads would hold up the LDS waits below
             FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
             if (r < nU) {
                 const int len = U.u_len[ub + r], aux = U.u_aux[ub + r];
@@ -1067,7 +1067,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     if (h2 != FIG_NOPOS && (h2 < w.lo || h2 > w.hi || h2 == h1)) h2 = FIG_NOPOS;
                     if (h1 == FIG_NOPOS) { h1 = h2; h2 = FIG_NOPOS; }
                     part = h1 != FIG_NOPOS;
-                    pkl = U.packed + U.u_woff[ub + r];
+                    pkl = (fig_gcu32p)U.packed + U.u_woff[ub + r];
                 }
             }
             if (!fig_wave_any(part)) continue;
@@ -1081,8 +1081,10 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                     const bool two = fig_wave_any(ev && c2 != FIG_NOPOS);
                     const int xa = (ev ? c1 : 0) + xoff, xb = (ev && c2 != FIG_NOPOS ? c2 : (ev ? c1 : 0)) + xoff;
                     double qa = 1, qb = 1;
+                    uint32_t wd_nx = ev ? pkl[0] : 0u;
                     for (int wi = 0; wi < nw2f; wi++) {
-                        const uint32_t wd = ev ? pkl[wi] : 0u;
+                        const uint32_t wd = wd_nx;                          // fetched a word (16 steps) ahead
+                        if (wi + 1 < nw2f) wd_nx = ev ? pkl[wi + 1] : 0u;
                         const int j0 = wi * 16;
                         int nb = Lfull - j0; if (nb > 16) nb = 16;
                         if (nb == 16) {
@@ -1493,7 +1495,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
             const bool mine = r < nU && mdone[r];
             if (!fig_wave_any(mine)) continue;
             bool acc = false; int of = 0, len = 0; double tlv = 0;
-            const uint32_t *pkl = U.packed;
+            fig_gcu32p pkl = (fig_gcu32p)U.packed;          // global view: a generic pointer's FLAT loads would hold up the LDS waits below
             FigWin w; w.lo = 0; w.hi = -1; w.tis0 = 0; w.dir = 1;
             if (mine) {
                 len = U.u_len[ub + r];
@@ -1501,7 +1503,7 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
                 tlv = -fig_log10(E.scr.hval[r]);
                 acc = tlv < U.cutoff;
                 if (mode == 1) acc = acc && E.scr.saved[r] == 1;
-                pkl = U.packed + U.u_woff[ub + r];
+                pkl = (fig_gcu32p)U.packed + U.u_woff[ub + r];
                 w = fig_window_u(U, U.u_pos[ub + r], len, gapoffset);
                 E.scr.accf[r] = acc ? 1 : 0;
             }

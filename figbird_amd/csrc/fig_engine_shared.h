@@ -137,13 +137,6 @@ FIG_FI void fig_weights_n(const double (&x)[N], double (&w)[N]) {
     }
 }
 
-// Global (address space 1) views of the slab and batch arrays the E-step touches.  fig_uptr() hands out generic pointers, and a
-// generic access is a FLAT instruction: it counts on lgkmcnt as well as vmcnt and returns out of order with LDS operations, so
-// with one in flight every LDS wait becomes lgkmcnt(0) and also waits for the L2 round trip of the product rows.  global_load /
-// global_store count on vmcnt alone.
-typedef double __attribute__((address_space(1))) *fig_gdp;
-typedef const double __attribute__((address_space(1))) *fig_gcdp;
-typedef const uint32_t __attribute__((address_space(1))) *fig_gcu32p;
 // FigState lives in LDS; through E.S (a generic pointer) its fields are FLAT loads too: the staging arrays go through this view
 typedef FigState __attribute__((address_space(3))) *fig_lsp;
 
