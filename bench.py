@@ -12,17 +12,19 @@ over gaps drawn from the synthetic set's distribution: scaffolds of 50 kb with a
 gap-length mix, 2x150-bp reads with insert N(3500, 350), mean 10^3 reads per gap (10^8 reads / 10^5 gaps, capped
 at 3000 as Preprocess does), 0.5 % substitutions.  A bit-exact fill of the whole 10^5-gap set is ~10^17 FP64
 flops (hours on any hardware, CPU-years for the reference), so a "step" is one fill pass over a fixed seeded
-sample of `--gaps-per-gpu` x N gaps of that distribution, resident in HBM (`full_set_seconds_est` extrapolates).
+sample of that distribution, resident in HBM (`full_set_seconds_est` extrapolates).
 
 Multi-GPU: every rank generates the same global sample (same seed), the product's partitioner
 (figbird_amd.dist.partition_lpt on estimate_cost: the role of FillGaps.cpp:456-649) deals it into N shards, each rank
 fills its shard through the C ABI, and one all-gather of packed byte buffers per step reassembles the results.
-`--scaling weak` (default): the sample is `--gaps-per-gpu` x N gaps; `--scaling strong`: one fixed set of `--total-gaps`
-gaps whatever N is (BASELINE's metric is one 10^5-gap set at 1/2/4/8 GPUs; the default total is 8 x `--gaps-per-gpu`).
+`--scaling strong` (default): ONE fixed seeded set of `--total-gaps` gaps (default 8 x `--gaps-per-gpu` = 4096) whatever N is
+-- BASELINE's metric is one set filled at 1/2/4/8 GPUs, so N = 1 fills all 4096 gaps per step and N = 8 fills 512 per rank;
+`--scaling weak`: the sample is `--gaps-per-gpu` x N gaps.
 
-Wall budget: the whole run (imports, generation, CPU baseline, partial pass, warm-up and timed steps) is kept
-inside `--budget-s` seconds.  The first fill is timed; warm-up and step counts are then clamped to what fits and
-the line reports the counts actually run (`steps`, `warmup`) beside `requested_steps` / `requested_warmup`.
+Wall budget: the whole run (imports, generation, warm-up and timed steps, then the CPU baseline, the partial pass and the
+per-bracket probes) is kept inside `--budget-s` seconds.  The first fill is timed; warm-up and step counts are then clamped
+to what fits (with a reserve for the extras that follow the timed loop) and the line reports the counts actually run
+(`steps`, `warmup`) beside `requested_steps` / `requested_warmup`.
 One JSON line on stdout (rank 0), also when the budget runs out or the process receives SIGTERM."""
 from __future__ import annotations
 
@@ -111,8 +113,12 @@ def launch_ranks(n, argv):
     return 0
 
 
+def n_set_of(args, world):
+    return (args.total_gaps or 8 * args.gaps_per_gpu) if args.scaling == "strong" else args.gaps_per_gpu * world
+
+
 def workload_key(args, world):
-    return f"{args.mode}|{args.mix}|g{args.gaps_per_gpu}|r{args.reads_per_gap:g}|s{args.seed}|n{world}"
+    return f"{args.mode}|{args.mix}|set{n_set_of(args, world)}|r{args.reads_per_gap:g}|s{args.seed}|n{world}"
 
 
 def main():
@@ -120,7 +126,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("FIGBENCH_BUDGET_S", "430")),
+    ap.add_argument("--budget-s", type=float, default=float(os.environ.get("FIGBENCH_BUDGET_S", "540")),
                     help="wall budget of the whole run; warm-up/steps are clamped to fit")
     ap.add_argument("--gaps-per-gpu", type=int, default=512)
     ap.add_argument("--reads-per-gap", type=float, default=1000.0)
@@ -130,7 +136,7 @@ def main():
     ap.add_argument("--cpu-baseline", type=int, default=1)
     ap.add_argument("--partial-pass", type=int, default=1, help="also report the partial-mode pass (untimed extra)")
     ap.add_argument("--cpu-sample-gaps", type=int, default=0, help="0 = five gaps per host core from the >400-bp bracket")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"], help="weak: gaps-per-gpu x N gaps; strong: one fixed set of --total-gaps")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"], help="strong: one fixed set of --total-gaps for every N; weak: gaps-per-gpu x N gaps")
     ap.add_argument("--total-gaps", type=int, default=0, help="size of the fixed set of --scaling strong (0 = 8 x gaps-per-gpu)")
     ap.add_argument("--bracket-probes", type=int, default=1, help="measure the cheap per-bracket probes inside this run (N=1 only)")
     args = ap.parse_args()
@@ -189,7 +195,7 @@ def main():
                                  read_length=spec.read_len, neg_overlap=30, partial_len=mc.partial_len)
 
     # ---- the global sample (identical on every rank) and this rank's shard of it
-    n_set = (args.total_gaps or 8 * args.gaps_per_gpu) if args.scaling == "strong" else args.gaps_per_gpu * world
+    n_set = n_set_of(args, world)
     gbatch, truth = synth.make_bench_batch(args.seed, n_set, spec)
     n_global = gbatch.n_gaps
     off = gbatch.u_read_off if spec.mode == "unmapped" else gbatch.p_read_off
@@ -235,53 +241,29 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, seeded sample of "
                                + (f"{args.gaps_per_gpu} gaps/GPU" if args.scaling == "weak" else f"{n_global} gaps in all (fixed set)") + f" from the {args.mix} gap mix",
-                   "gaps_per_gpu": args.gaps_per_gpu, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
+                   "gaps_per_gpu": n_global / world, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
                    "insert": [spec.insert_mean, spec.insert_sd], "substitution_rate": spec.err,
                    "sharding": f"{n_global} gaps dealt LPT on estimated cost over {world} rank(s), no data-path collective, 1 all-gather of packed results per step"},
     })
 
     # ---- first fill: timed on its own, counts as warm-up; everything after it is clamped to the budget
+    # (--warmup 0: no first fill and no clamping -- exactly --steps fills, for the profiler passes of tools/profile_bench.sh)
     barrier()
-    t0 = time.perf_counter()
-    res, filled, st = one_step()
-    barrier()
-    t_first = allmax(time.perf_counter() - t0)
-    warm_done = 1
-    log(f"first fill {t_first:.1f} s ({st['kernel_ms'] / 1e3:.1f} s of kernels), {left():.0f} s of budget left")
+    if args.warmup > 0:
+        t0 = time.perf_counter()
+        res, filled, st = one_step()
+        barrier()
+        t_first = allmax(time.perf_counter() - t0)
+        warm_done = 1
+        log(f"first fill {t_first:.1f} s ({st['kernel_ms'] / 1e3:.1f} s of kernels), {left():.0f} s of budget left")
+    else:
+        t_first, warm_done = 0.0, 0
 
-    # ---- CPU baseline + the other mode's pass (rank 0, N=1 only), before the timed loop and inside the budget
-    extras_s = 0.0
-    if rank == 0 and world == 1 and args.cpu_baseline:
-        if left() > 2.5 * t_first + 75:
-            t = time.perf_counter()
-            try:
-                OUT["cpu_baseline"] = cpu_baseline(args, spec, batch, mc, res, eng, work, st, left() - 2.5 * t_first - 20)
-            except Exception as e:  # pragma: no cover
-                OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
-            extras_s += time.perf_counter() - t
-            log(f"cpu_baseline done in {time.perf_counter() - t:.1f} s")
-        else:
-            OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "reference", "sample": "skipped: wall budget too short"}
-    if rank == 0 and world == 1 and args.mode == "unmapped" and args.partial_pass and left() > 2.5 * t_first + 30:
-        t = time.perf_counter()
-        try:
-            OUT["partial_pass"] = partial_pass(args, local, work)
-        except Exception as e:  # pragma: no cover
-            OUT["partial_pass"] = {"value": None, "unit": "gaps/s", "note": f"failed: {e!r}"}
-        extras_s += time.perf_counter() - t
-
-    if rank == 0 and world == 1 and args.mode == "unmapped" and args.bracket_probes and left() > 2.5 * t_first + 40:
-        t = time.perf_counter()
-        try:
-            OUT["per_bracket"] = bracket_probes(args, eng, batch, spec, min(45.0, left() - 2.5 * t_first - 10))
-        except Exception as e:  # pragma: no cover
-            OUT["per_bracket"] = {"note": f"failed: {e!r}"}
-        extras_s += time.perf_counter() - t
-        log(f"bracket probes done in {time.perf_counter() - t:.1f} s")
-
-    # ---- clamp warm-up and steps to what is left (10 s reserve for teardown); timed steps come first
+    # ---- clamp warm-up and steps to what is left (10 s reserve for teardown); the timed steps come before the extras
+    # N = 1 keeps a reserve for the extras that follow the timed loop (CPU baseline ~60 s, partial pass ~10 s, bracket probes ~35 s)
+    extras_reserve = 110.0 if (world == 1 and (args.cpu_baseline or args.partial_pass or args.bracket_probes)) else 0.0
     left_min = -allmax(-left())                       # the rank with the least budget left decides
-    fit = int(max(0.0, left_min - 10.0) / max(t_first, 1e-3))
+    fit = int(max(0.0, left_min - 10.0 - extras_reserve) / max(t_first, 1e-3)) if warm_done else args.steps
     steps = max(1, min(args.steps, fit))
     warm_more = max(0, min(args.warmup - warm_done, fit - steps))
     if world > 1:
@@ -342,17 +324,6 @@ def main():
                 "frac": alg_bytes / max(ksec, 1e-12) / 1e9 / HBM_PEAK_GBS, "alg_bytes_per_step": alg_bytes / steps,
                 "note": "path is FP64-ALU bound (~1e5-1e7 flop/byte); HBM figure reported because the north star asks for it"}}
     if st.get("spec_flops", 0) > 0 and st.get("mle_alg_flops", 0) > 0:
-        # LDS is the roof that binds the pair-chain form of the E-step: 16 B of table per chain step (4 flops) and
-        # 8 B of weight row per pile-up add.  chain steps S = the MLE term (1 flop per step), adds A = alg - 5 S.
-        S_steps = st["mle_alg_flops"] * (st["alg_flops"] / st["spec_flops"])
-        A_adds = max(0.0, st["alg_flops"] - 5.0 * S_steps)
-        lds_bytes = 16.0 * S_steps + 8.0 * A_adds
-        lds_peak = 256 * 256 * 2.4e9                         # 256 CUs x 256 B/clk x 2.4 GHz
-        step_ksec = st["kernel_ms"] / 1e3
-        OUT["roofline"]["lds"] = {"bytes_per_step_pair_chain_form": lds_bytes, "peak": lds_peak / 1e12, "unit": "TB/s",
-                                  "achieved": lds_bytes / max(step_ksec, 1e-12) / 1e12, "frac": lds_bytes / max(step_ksec, 1e-12) / lds_peak,
-                                  "note": "LDS bytes the one-table-read-per-chain-step form needs (16 B per E-step chain step + 8 B per pile-up add), last step, vs 256 CU x 256 B/clk; "
-                                          "an E-step that shares the per-column factors between the reads of a chunk needs fewer (DESIGN §4a)"}
         # credited flops the device really executed: everything but the pruned part of the MLE term (ratios taken over all
         # evaluations of the last step, discarded speculation included)
         mle_share = st["mle_alg_flops"] / st["spec_flops"]
@@ -361,6 +332,36 @@ def main():
         OUT["roofline"]["mle_fraction_executed"] = mle_done
         OUT["roofline"]["executed_frac"] = OUT["roofline"]["frac"] * (1.0 - mle_share * (1.0 - mle_done))
         OUT["roofline"]["discarded_speculation_frac"] = max(0.0, 1.0 - st["alg_flops"] / st["spec_flops"])
+    # ---- CPU baseline, the other mode's pass and the per-bracket probes (rank 0, N=1 only): after the timed loop, inside what is left of the budget
+    extras_s = 0.0
+    if rank == 0 and world == 1 and args.cpu_baseline:
+        if left() > 45:
+            t = time.perf_counter()
+            try:
+                OUT["cpu_baseline"] = cpu_baseline(args, spec, batch, mc, res, eng, work, st, min(left() - 20, 110.0))
+            except Exception as e:  # pragma: no cover
+                OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "port", "sample": f"failed: {e!r}"}
+            extras_s += time.perf_counter() - t
+            log(f"cpu_baseline done in {time.perf_counter() - t:.1f} s")
+        else:
+            OUT["cpu_baseline"] = {"value": None, "unit": "gaps/s", "cores": 0, "kind": "reference", "sample": "skipped: wall budget too short"}
+    if rank == 0 and world == 1 and args.mode == "unmapped" and args.partial_pass and left() > 25:
+        t = time.perf_counter()
+        try:
+            OUT["partial_pass"] = partial_pass(args, local, work)
+        except Exception as e:  # pragma: no cover
+            OUT["partial_pass"] = {"value": None, "unit": "gaps/s", "note": f"failed: {e!r}"}
+        extras_s += time.perf_counter() - t
+
+    if rank == 0 and world == 1 and args.mode == "unmapped" and args.bracket_probes and left() > 30:
+        t = time.perf_counter()
+        try:
+            OUT["per_bracket"] = bracket_probes(args, eng, batch, spec, min(45.0, left() - 12))
+        except Exception as e:  # pragma: no cover
+            OUT["per_bracket"] = {"note": f"failed: {e!r}"}
+        extras_s += time.perf_counter() - t
+        log(f"bracket probes done in {time.perf_counter() - t:.1f} s")
+
     if "cpu_baseline" in OUT and OUT["cpu_baseline"].get("gflops"):
         cb = OUT["cpu_baseline"]
         # same-mix figure: the reference does the same algorithmic flops per gap (control flow is bit-identical), so the
@@ -437,23 +438,21 @@ def csrc_sha():
 
 
 def read_traffic(args, world):
-    """HBM bytes per step from the PMC passes of this same command (tools/profile_bench.sh writes the sidecar from
-    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters cannot be read from inside the process)."""
+    """HBM bytes per step AND PER GPU (like roofline.achieved / alg_flops_per_step) from the PMC passes of this same command at
+    N = 1 (tools/profile_bench.sh writes the sidecar from `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` runs; counters
+    cannot be read from inside the process).  N > 1 is scaled from the 1-GPU pass: no PMC pass is run on the multi-GPU node."""
     try:
         sc = json.load(open(TRAFFIC_SIDECAR))
-        ent = sc.get(workload_key(args, world))
-        if not ent and world > 1:
-            # weak scaling: every rank fills a 512-gap shard of the same mix, so the whole-job traffic is taken as the 1-GPU
-            # pass x ranks (no PMC pass is run on the multi-GPU node)
-            e1 = sc.get(workload_key(args, 1))
-            if e1:
-                return e1["bytes_per_step"] * world, e1.get("note", "") + f" x {world} ranks, scaled from the 1-GPU PMC pass (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')})"
-        if ent:
-            stale = ""
-            if sc.get("csrc_sha") and sc.get("csrc_sha") != csrc_sha():
-                stale = "; STALE: the PMC passes were recorded with other kernel sources (csrc hash differs)"
-            return ent["bytes_per_step"], ent.get("note", "") + f" (source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')}{stale})"
-        return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"
+        src = f"(source: {os.path.relpath(TRAFFIC_SIDECAR, ROOT)}, head {sc.get('head', '?')}"
+        stale = "; STALE: the PMC passes were recorded with other kernel sources (csrc hash differs)" if sc.get("csrc_sha") and sc.get("csrc_sha") != csrc_sha() else ""
+        ent = sc.get(workload_key(args, 1))
+        if not ent:
+            return None, "no PMC pass recorded for this workload key in profiles/traffic_sidecar.json"
+        if world == 1:
+            return ent["bytes_per_step"], ent.get("note", "") + f" {src}{stale})"
+        if args.scaling == "strong":        # the same set split over N ranks: each GPU moves ~1/N of the 1-GPU pass
+            return ent["bytes_per_step"] / world, ent.get("note", "") + f" / {world} ranks, scaled from the 1-GPU PMC pass of the same set {src}{stale})"
+        return ent["bytes_per_step"], ent.get("note", "") + f" per rank (every rank fills a shard of the size of the 1-GPU pass) {src}{stale})"
     except Exception as e:
         return None, f"profiles/traffic_sidecar.json unreadable: {e!r}"
 

@@ -66,7 +66,7 @@ class FigStats(C.Structure):
 
 EXPORTS = ["fig_version", "fig_strerror", "fig_ctx_create", "fig_ctx_destroy", "fig_ctx_set_model",
            "fig_results_capacity", "fig_batch_upload", "fig_fill_resident", "fig_batch_free", "fig_fill_gaps",
-           "fig_get_stats"]
+           "fig_get_stats", "fig_batch_probe_reach", "fig_batch_set_ot_preset"]
 
 _lib = None
 _host = None
@@ -96,6 +96,8 @@ def load_library(path: Optional[str] = None) -> C.CDLL:
     lib.fig_batch_free.restype = None
     lib.fig_fill_gaps.argtypes = [C.c_void_p, C.POINTER(FigGapBatch), C.POINTER(FigGapResults)]
     lib.fig_get_stats.argtypes = [C.c_void_p, C.POINTER(FigStats)]
+    lib.fig_batch_probe_reach.argtypes = [C.c_void_p, c_u8_p]
+    lib.fig_batch_set_ot_preset.argtypes = [C.c_void_p, c_u8_p]
     if path is None:
         _lib = lib
     return lib
@@ -117,6 +119,7 @@ def load_host_library() -> C.CDLL:
         _host.fighost_run_message.argtypes = [C.c_void_p, C.c_int]; _host.fighost_run_message.restype = C.c_char_p
         _host.fighost_run_model.argtypes = [C.c_void_p, C.POINTER(FigModel)]
         _host.fighost_run_shard.argtypes = [C.c_void_p, c_i64_p, C.c_int64, C.POINTER(FigGapBatch), c_i64_p, c_i64_p]
+        _host.fighost_run_ot_presets.argtypes = [C.c_void_p, c_u8_p, c_u8_p]
         _host.fighost_run_write.argtypes = [C.c_void_p, c_i32_p, c_i32_p, c_i64_p, C.c_char_p, c_i32_p, c_i32_p, c_i32_p, C.c_char_p, C.c_int]
     return _host
 
@@ -345,9 +348,33 @@ class Engine:
     def free_batch(self):
         self.lib.fig_batch_free(self.ctx)
 
-    def fill_struct(self, cbatch: "FigGapBatch", n_ureads: int, n_preads: int, draw: bool = True) -> FillResult:
+    def probe_reach(self) -> np.ndarray:
+        """uint8[n_gaps] of the resident batch: 1 = the gap's candidate loop gets to Figbird.cpp:6317 (fig_batch_probe_reach)."""
+        r = np.zeros(max(self.n_gaps, 1), dtype=np.uint8)
+        if self.n_gaps > 0:
+            self._check(self.lib.fig_batch_probe_reach(self.ctx, _p(r, c_u8_p)), "fig_batch_probe_reach")
+        return r[:self.n_gaps]
+
+    def set_ot_preset(self, preset: np.ndarray):
+        """Replace `gap_ot_preset` of the resident batch (fig_batch_set_ot_preset)."""
+        a = np.ascontiguousarray(preset, dtype=np.uint8)
+        if len(a) != self.n_gaps:
+            raise ValueError("set_ot_preset: one entry per gap of the resident batch")
+        if self.n_gaps > 0:
+            self._check(self.lib.fig_batch_set_ot_preset(self.ctx, _p(a, c_u8_p)), "fig_batch_set_ot_preset")
+
+    def upload_struct(self, cbatch: "FigGapBatch"):
+        """fig_batch_upload of a caller-built `fig_gap_batch` (e.g. a shard view from libfighost's run handle)."""
+        self._cb = cbatch
+        self.n_gaps = int(cbatch.n_gaps)
+        self.cap = int(self.lib.fig_results_capacity(C.byref(self._cm), C.byref(cbatch))) if self.n_gaps > 0 else 1
+        if self.n_gaps > 0:
+            self._check(self.lib.fig_batch_upload(self.ctx, C.byref(cbatch)), "fig_batch_upload")
+
+    def fill_struct(self, cbatch: "FigGapBatch", n_ureads: int, n_preads: int, draw: bool = True, resident: bool = False) -> FillResult:
         """fig_fill_gaps on a caller-built `fig_gap_batch` (e.g. a shard view from libfighost's run handle), with the
-        per-read draw planes; returns a FillResult whose `draw` field holds (draw_pos, draw_isz, draw_len)."""
+        per-read draw planes; returns a FillResult whose `draw` field holds (draw_pos, draw_isz, draw_len).
+        resident=True: the batch was uploaded with upload_struct (fig_fill_resident + fig_batch_free)."""
         n = int(cbatch.n_gaps)
         cap = int(self.lib.fig_results_capacity(C.byref(self._cm), C.byref(cbatch))) if n > 0 else 1
         fl = np.zeros(max(n, 1), dtype=np.int32); gt = np.zeros(max(n, 1), dtype=np.int32)
@@ -360,7 +387,12 @@ class Engine:
         dlen = np.full(max(2 * n, 1), -1, dtype=np.int32)
         if draw:
             r.draw_pos = _p(dpos, c_i32_p); r.draw_isz = _p(disz, c_i32_p); r.draw_len = _p(dlen, c_i32_p)
-        if n > 0:
+        if n > 0 and resident:
+            try:
+                self._check(self.lib.fig_fill_resident(self.ctx, C.byref(r)), "fig_fill_resident")
+            finally:
+                self.lib.fig_batch_free(self.ctx)
+        elif n > 0:
             self._check(self.lib.fig_fill_gaps(self.ctx, C.byref(cbatch), C.byref(r)), "fig_fill_gaps")
         res = FillResult(fl[:n].copy(), gt[:n].copy(), None, None, str_off=so, raw=st)
         res.draw = (dpos[:nr], disz[:nr], dlen[:2 * n])

@@ -15,6 +15,7 @@
 #include <vector>
 #include <chrono>
 #include <thread>
+#include <mutex>
 
 #include "../../include/figbird_hip.h"
 #include "fig_engine.h"
@@ -129,6 +130,28 @@ __global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_begin_kernel(FigD
     }
     if (E.flops) atomicAdd(&B.counters[1], E.flops);
     FIG_FLUSH_MLE();
+}
+
+// ---- pre-pass (partial mode): per gap, does its candidate loop get to Figbird.cpp:6317?  -> gapctl[gi*4+3]
+template <bool LDS_TAB, int NT>
+__global__ void __launch_bounds__(NT, (NT <= 256 ? 2 : 1)) fig_probe_kernel(FigDevModel M, FigDevBatch B, FigKernArgs A) {
+    FigEng E; FigScr work;
+    fig_eng_init(E, M, B, A, LDS_TAB, work);
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.queue_head[A.qsel ^ 1] = 0;      // the next launch of this lane pops from the other head
+    while (true) {
+        if (E.tid == 0) E.S->bc_i = atomicAdd(B.queue_head + A.qsel, 1);
+        __syncthreads();
+        int qi = A.q_begin + E.S->bc_i;
+        __syncthreads();
+        if (qi >= A.q_end) break;
+        int gi = B.order[qi];
+        E.g = &B.gaps[gi];
+        FigPersist P; fig_persist_of(B, *E.g, P);
+        fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+        const int reach = fig_gap_probe<LDS_TAB>(E);
+        if (E.tid == 0) B.gapctl[gi * 4 + 3] = reach;
+        __syncthreads();
+    }
 }
 
 // ---- kernel 2: speculative candidate evaluations; items = {gap, candidate index j, slot, -}
@@ -267,6 +290,9 @@ struct fig_ctx {
     int nslots = 32;
     std::vector<FigLane> lanes;
     fig_stats stats;
+    int sh_on = FIG_SH_SC;            // FIG_ESTEP / FIG_SH_CHUNKS, read once at fig_ctx_create
+    std::vector<uint8_t> h_ot;        // host copy of db.ot_preset
+    uint8_t *d_ot = nullptr;
 };
 
 static int dev_alloc(fig_ctx *ctx, size_t bytes, void **out) {
@@ -315,7 +341,8 @@ extern "C" int fig_ctx_create(int device_ordinal, fig_ctx **out) {
     // GPU_MAX_HW_QUEUES hardware queues (default 4), and two lanes' persistent kernels on one queue serialise.  Asking for 8
     // is worth 1 % of the bench step.  Only effective when this is the process's first HIP call (figfill); a host that
     // initialises HIP earlier sets the variable itself (bench.py and figfill_mp do).
-    setenv("GPU_MAX_HW_QUEUES", "8", 0);
+    static std::once_flag env_once;   // contexts may be created from several host threads (figfill with FIGFILL_DEVICES sets it in main() already)
+    std::call_once(env_once, [] { setenv("GPU_MAX_HW_QUEUES", "8", 0); });
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return FIG_ENODEV;
     if (device_ordinal < 0 || device_ordinal >= n) return FIG_ENODEV;
@@ -331,6 +358,8 @@ extern "C" int fig_ctx_create(int device_ordinal, fig_ctx **out) {
         return FIG_EHIP;
     }
     memset(&ctx->stats, 0, sizeof(ctx->stats));
+    { const char *ev = getenv("FIG_ESTEP"); const char *sc = getenv("FIG_SH_CHUNKS");
+      ctx->sh_on = (ev && !strcmp(ev, "pair")) ? 0 : (sc ? std::max(1, std::min(FIG_SH_SC, atoi(sc))) : FIG_SH_SC); }
     *out = ctx;
     return FIG_OK;
 }
@@ -338,6 +367,7 @@ extern "C" int fig_ctx_create(int device_ordinal, fig_ctx **out) {
 static void free_batch(fig_ctx *ctx) {
     for (auto &b : ctx->bufs) if (b.p) hipFree(b.p);
     ctx->bufs.clear();
+    ctx->d_ot = nullptr;
     ctx->have_batch = false;
     ctx->classes.clear();
     for (auto &l : ctx->lanes) { if (l.stream) hipStreamDestroy(l.stream); if (l.done) hipEventDestroy(l.done); if (l.h_ctl) hipHostFree(l.h_ctl); if (l.h_items) hipHostFree(l.h_items); if (l.h_entries) hipHostFree(l.h_entries); }
@@ -422,6 +452,8 @@ extern "C" int64_t fig_results_capacity(const fig_model *m, const fig_gap_batch 
     return fig_pack_results_capacity(m, b);
 }
 
+static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel = 0);
+
 extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if (!ctx || !b) return FIG_EINVAL;
     if (!ctx->have_model) return FIG_EINVAL;
@@ -474,8 +506,12 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if (m->unmapped_flag) {
         if ((rc = dev_alloc(ctx, (size_t)K.stream_total * 4, &p))) return rc;
         db.ustream = (const uint32_t *)p;
-        FIG_HIP(hipMemsetAsync(p, 0, (size_t)K.stream_total * 4, ctx->stream));
-        if (ng > 0) hipLaunchKernelGGL(fig_stream_kernel, dim3((unsigned)std::min<int64_t>(ng, 4096)), dim3(256), 0, ctx->stream, ctx->dm, db, (uint32_t *)p);
+        // every entry starts as "select the constant 1.0" in both halves: a slot the kernel does not write never switches indexing off
+        FIG_HIP(hipMemsetD32Async((hipDeviceptr_t)p, (int)(((0x1000u | FIG_SH_ONE) << 16) | (0x1000u | FIG_SH_ONE)), (size_t)K.stream_total, ctx->stream));
+        if (ng > 0) {
+            hipLaunchKernelGGL(fig_stream_kernel, dim3((unsigned)std::min<int64_t>(ng, 4096)), dim3(256), 0, ctx->stream, ctx->dm, db, (uint32_t *)p);
+            FIG_HIP(hipGetLastError());
+        }
     }
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.filled_len = (int32_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)ng * 4, &p))) return rc; db.gaptofill = (int32_t *)p;
@@ -488,6 +524,9 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     if ((rc = dev_alloc(ctx, (size_t)stride * std::max<size_t>(total_blocks, 1), &p))) return rc; db.scratch = (uint8_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)K.persist_total + 256, &p))) return rc; db.persist = (uint8_t *)p;
     if ((rc = dev_alloc(ctx, (size_t)std::max<int64_t>(ng, 1) * 16, &p))) return rc; db.gapctl = (int32_t *)p;
+    if ((rc = dev_alloc(ctx, (size_t)std::max<int64_t>(ng, 1), &p))) return rc; ctx->d_ot = (uint8_t *)p; db.ot_preset = ctx->d_ot;
+    ctx->h_ot = K.ot_preset;
+    FIG_HIP(hipMemcpyAsync(ctx->d_ot, ctx->h_ot.data(), (size_t)std::max<int64_t>(ng, 1), hipMemcpyHostToDevice, ctx->stream));
     ctx->nslots = K.nslots;
     {   size_t blk = 0;
         for (size_t ci = 0; ci < ctx->classes.size(); ci++) {
@@ -516,6 +555,52 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     ctx->stats.h2d_ms = ms;
     ctx->stats.packed_bytes = K.packed_bytes();
     ctx->have_batch = true;
+    if (!K.ot_given && m->partial_flag && ng > 0) {
+        // no carry given: the batch is ONE worker process of the reference taking its gaps in batch order -- measure which
+        // gaps get to Figbird.cpp:6317 and hand every gap the prefix-OR of its predecessors
+        std::vector<uint8_t> reach((size_t)ng, 0), preset((size_t)ng, 0);
+        if ((rc = fig_batch_probe_reach(ctx, reach.data()))) { free_batch(ctx); return rc; }
+        std::vector<int64_t> ids((size_t)ng);
+        for (int64_t g = 0; g < ng; g++) ids[(size_t)g] = g;
+        fig_ot_carry(ids, reach.data(), preset.data());
+        if ((rc = fig_batch_set_ot_preset(ctx, preset.data()))) { free_batch(ctx); return rc; }
+    }
+    return FIG_OK;
+}
+
+// Per gap of the resident batch: 1 iff the gap's candidate loop gets to Figbird.cpp:6317 (fig_engine_sched.h: fig_gap_probe).
+// Partial mode: one cheap launch per class (setup + the first initialize(), no EM); unmapped mode: all 0 (overlap_threshold is
+// never read there, see fig_gap_probe).
+extern "C" int fig_batch_probe_reach(fig_ctx *ctx, uint8_t *reach) {
+    if (!ctx || !reach || !ctx->have_batch) return FIG_EINVAL;
+    hipSetDevice(ctx->device);
+    const int64_t ng = ctx->n_gaps;
+    memset(reach, 0, (size_t)ng);
+    if (!ctx->hm.partial_flag || ng == 0) return FIG_OK;
+    FigDevBatch db = ctx->db;
+    db.dbg_n_cand = nullptr; db.dbg_cand_i = nullptr; db.dbg_cand_lik = nullptr; db.dbg_max_cand = 0; db.dbg_n_place = nullptr;
+    db.draw_pos = db.draw_isz = db.draw_len = nullptr;
+    db.dbg_counts = db.dbg_read_maxlv = nullptr; db.dbg_plane_cols = db.dbg_plane_reads = 0;
+    FIG_HIP(hipMemsetAsync(db.gapctl, 0, (size_t)ng * 16, ctx->stream));
+    for (const fig_ctx::Cls &c : ctx->classes) {
+        FIG_HIP(hipMemsetAsync(db.queue_head, 0, 8, ctx->stream));
+        FIG_HIP(launch_any(ctx, c, db, ctx->stream, 4, c.blocks, nullptr, 0));
+    }
+    std::vector<int32_t> ctl((size_t)ng * 4);
+    FIG_HIP(hipMemcpyAsync(ctl.data(), db.gapctl, (size_t)ng * 16, hipMemcpyDeviceToHost, ctx->stream));
+    FIG_HIP(hipStreamSynchronize(ctx->stream));
+    for (int64_t g = 0; g < ng; g++) reach[g] = ctl[(size_t)g * 4 + 3] ? 1 : 0;
+    return FIG_OK;
+}
+
+// Replaces fig_gap_batch::gap_ot_preset of the resident batch (a caller that fills a shard of a run: probe every shard,
+// exchange the bits, carry them along the reference's worker processes -- fig_gaprules.h -- and set the result here).
+extern "C" int fig_batch_set_ot_preset(fig_ctx *ctx, const uint8_t *preset) {
+    if (!ctx || !preset || !ctx->have_batch) return FIG_EINVAL;
+    hipSetDevice(ctx->device);
+    const int64_t ng = ctx->n_gaps;
+    for (int64_t g = 0; g < ng; g++) ctx->h_ot[(size_t)g] = preset[g] ? 1 : 0;
+    if (ng > 0) { FIG_HIP(hipMemcpy(ctx->d_ot, ctx->h_ot.data(), (size_t)ng, hipMemcpyHostToDevice)); }
     return FIG_OK;
 }
 
@@ -526,16 +611,15 @@ static FigKernArgs kargs_of(const fig_ctx::Cls &c) {
     A.tiles = c.c.tiles; A.tile_step = c.c.tile_step; A.tile_cols = c.c.tile_cols; A.tiled_max = c.c.tiled_max;
     // FIG_ESTEP=pair: the pair-chain E-step everywhere (A/B runs, tests); FIG_SH_CHUNKS=<1..4>: chunks per super-chunk of the
     // shared-factor E-step (fig_engine_shared.h; default 4: bench step 24.3 s with 2, 23.9 s with 4)
-    { const char *ev = getenv("FIG_ESTEP"); const char *sc = getenv("FIG_SH_CHUNKS");
-      A.sh_on = (ev && !strcmp(ev, "pair")) ? 0 : (sc ? std::max(1, std::min(FIG_SH_SC, atoi(sc))) : FIG_SH_SC); }
+    A.sh_on = 0;                       // set by launch_kind from the context (the environment is read once, at fig_ctx_create)
     return A;
 }
 
-// kind: 0 sequential fill, 1 begin, 2 eval (items), 3 end (list)
+// kind: 0 sequential fill, 1 begin, 2 eval (items), 3 end (list), 4 probe (reach bits)
 template <bool LDS_TAB, int NT>
 static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel) {
     FigKernArgs A = kargs_of(c);
-    A.qsel = qsel;
+    A.qsel = qsel; A.sh_on = ctx->sh_on;
     hipError_t e = hipSuccess;
     if (kind == 0) {
         auto k = fig_fill_kernel<LDS_TAB, NT>;
@@ -552,6 +636,11 @@ static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevB
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
         if (e != hipSuccess) return e;
         hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A, (const int4 *)list, n);
+    } else if (kind == 4) {
+        auto k = fig_probe_kernel<LDS_TAB, NT>;
+        e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(k, dim3(blocks), dim3(NT), c.c.lds, stream, ctx->dm, db, A);
     } else {
         auto k = fig_end_kernel<LDS_TAB, NT>;
         e = hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.c.lds);
@@ -561,7 +650,7 @@ static hipError_t launch_kind(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevB
     return hipGetLastError();
 }
 
-static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel = 0) {
+static hipError_t launch_any(fig_ctx *ctx, const fig_ctx::Cls &c, const FigDevBatch &db, hipStream_t stream, int kind, int blocks, const void *list, int n, int qsel) {
     if (c.c.tiles > 0) return launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);      // LDS-tiled: the LDS code path with a streamed table
     if (c.c.lds_tab) return c.c.nt == 256 ? launch_kind<true, 256>(ctx, c, db, stream, kind, blocks, list, n, qsel) : launch_kind<true, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);
     return launch_kind<false, 512>(ctx, c, db, stream, kind, blocks, list, n, qsel);

@@ -21,11 +21,17 @@ FIG_D void fig_gap_begin(FigEng &E) {
         S.psr_temp[0] = S.psr_temp[1] = S.psr_final[0] = S.psr_final[1] = -1;
         S.umaxleftf = S.umaxrightf = S.ucoverf = 0;
         // overlap_threshold is a file-level global in the reference (Figbird.cpp:103), 0 until the first candidate loop of the
-        // process reaches :6317 and 5 ever after: a gap sees 5 if an EARLIER gap got there (g.pad, worked out by the packer in
-        // file order = the numthreads=1 order) or once its own loop does (fig_eval_candidate / fig_spec_replay)
-        S.num_itr = 0; S.overlap_threshold = g.pad ? 5 : 0; S.gaptofill = 0;
+        // process reaches :6317 and 5 ever after: a gap sees 5 if an EARLIER gap of its worker process got there (ot_preset:
+        // the prefix-OR, in the process's gap order, of the bits fig_gap_probe measures) or once its own loop does
+        // (fig_eval_candidate / fig_spec_replay)
+        S.num_itr = 0; S.overlap_threshold = (E.B->ot_preset && E.B->ot_preset[g.gapNo]) ? 5 : 0; S.gaptofill = 0;
         S.gl_len = S.gr_len = S.pl_len = S.pr_len = 0;
         S.cons_len = 1; E.scr.cons[0] = 4;
+        // used_read_arr is an uninitialised stack array in the reference (Figbird.cpp:6265); the one element it can read before
+        // writing is [0], when the loop leaves at its first candidate by side_limit < 10 in partial mode (:6303 -> :6547).  The
+        // reference's own builds disagree there (-O0: the stack residue is nonzero in ~70 % of sampled gaps, zero otherwise);
+        // the oracle and the engine take 0, i.e. the run(originalGap) + finalize(originalGap) branch
+        E.scr.used_read_arr[0] = 0;
         S.best_len = S.cur_len = S.prev_len = S.orig_len = 0;
         S.flops_useful = 0; S.n_place = 0; S.dbg_j = -1; S.pad_dj = 0;
         fig_flank_tables(E);
@@ -92,6 +98,23 @@ FIG_D void fig_gap_begin(FigEng &E) {
     }
     if (E.tid == 0 && S.L.range <= 0) S.L.done = 1;
     FIG_SYNC();
+}
+
+// ---- does this gap's candidate loop get to Figbird.cpp:6317 (`overlap_threshold=5`)?  The loop leaves before that line only
+// at its first candidate: no candidate at all (checkGapReads, :6292-6293), side_limit < 10 after the first initialize()
+// (:6303) or the gap closed by a negative overlap (:6305-6306); a later candidate is only reached past :6317.  None of this
+// reads overlap_threshold, so the bit can be measured before any gap is filled.  Partial mode only: the threshold is read
+// by detect_overlap_gapestimate alone (:2684, :2760-2766), whose callers are the partial placeReads (:3501) and the
+// `if(partial_flag==1)` block of finalize (:5512-5574), so an unmapped-mode run never looks at it.
+template <bool LDS>
+FIG_D int fig_gap_probe(FigEng &E) {
+    fig_gap_begin<LDS>(E);
+    FigState &S = *E.S;
+    if (S.L.range <= 0) return 0;
+    int fill = fig_initialize(E, S.L.gapEstimate, 0);
+    if (S.side_limit < 10) return 0;
+    if (S.one_side_repeat_flag == 1) fill = 0;
+    return !(fill != 0 && S.L.inr);
 }
 
 // ---- one candidate length: initialize + EM loop (+ the extra finalize-flag placeReads) + consensus (:6300-6356).

@@ -39,7 +39,7 @@ FIG_D unsigned fig_wave_max_u32(unsigned v) {
     return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
 }
 
-// ---- log10 for the E-step weights, ~40 FP64 operations against ~105 of the library's (which became a quarter of the E-step's
+// ---- log10 for the E-step weights (`fig_log10_fast` in DESIGN.md), ~40 FP64 operations against ~105 of the library's (which became a quarter of the E-step's
 // vector work once the chains cost 1.75 operations a step): x = m 2^e with m in [sqrt(1/2), sqrt(2)), s = (m-1)/(m+1) through
 // v_rcp_f64 + one Newton step with the quotient's rounding error recovered (s_lo), log m = 2 s + s z q(z) (atanh series in
 // z = s^2 to z^11), log10 x = e log10(2) + log m log10(e) assembled from hi/lo parts.  Against 80-bit log10l on 3e7 arguments
@@ -47,41 +47,12 @@ FIG_D unsigned fig_wave_max_u32(unsigned v) {
 // max error 1.87 ulp, > 1 ulp in 1.2e-5 of the arguments -- glibc's log10, which the reference calls, is > 1 ulp in 2.3e-4 of
 // them (max 1.58); the two agree bit for bit on 99.44 %.  Exact for 0 (-inf) and 1 (0).  Used for the weights only; the
 // per-read maximum (maxlv) keeps the library's log10.
-FIG_FI double fig_log10_fast(double x) {
-    double m = __builtin_amdgcn_frexp_mant(x);
-    int e = __builtin_amdgcn_frexp_exp(x);
-    const bool lowhalf = m < 0.70710678118654752440;
-    m = lowhalf ? m + m : m; e = lowhalf ? e - 1 : e;
-    const double a = m - 1.0, b = m + 1.0;
-    double r = __builtin_amdgcn_rcp(b);
-    { const double e0 = __builtin_fma(-b, r, 1.0); r = __builtin_fma(r, e0, r); }
-    const double s = a * r;
-    const double z = s * s;
-    double q = 2.0 / 23.0;
-    q = __builtin_fma(q, z, 2.0 / 21.0); q = __builtin_fma(q, z, 2.0 / 19.0); q = __builtin_fma(q, z, 2.0 / 17.0); q = __builtin_fma(q, z, 2.0 / 15.0);
-    q = __builtin_fma(q, z, 2.0 / 13.0); q = __builtin_fma(q, z, 2.0 / 11.0); q = __builtin_fma(q, z, 2.0 / 9.0); q = __builtin_fma(q, z, 2.0 / 7.0);
-    q = __builtin_fma(q, z, 2.0 / 5.0); q = __builtin_fma(q, z, 2.0 / 3.0);
-    const double s_lo = __builtin_fma(-s, b, a) * r;
-    const double t = s * z * q;
-    const double lm_hi = 2.0 * s;
-    const double lm_lo = __builtin_fma(2.0, s_lo, t);
-    const double L2hi = 0x1.34413509f78p-2, L2lo = 0x1.fef311f12b358p-46;      // log10(2): hi holds 41 bits, e * L2hi is exact
-    const double IE_hi = 0x1.bcb7b1526e50ep-2, IE_lo = 0x1.95355baaafad3p-57;    // log10(e)
-    const double ed = (double)e;
-    const double p_hi = lm_hi * IE_hi;
-    const double p_lo = __builtin_fma(lm_hi, IE_hi, -p_hi) + __builtin_fma(lm_hi, IE_lo, lm_lo * IE_hi);
-    const double r_hi = ed * L2hi;
-    double sum = r_hi + p_hi;
-    double err = (r_hi - sum) + p_hi;
-    if (e == 0) { sum = p_hi; err = 0.0; }
-    const double res = sum + (err + __builtin_fma(ed, L2lo, p_lo));
-    return x == 0.0 ? -__builtin_inf() : res;
-}
+// (This is the log10 stage of fig_weights_n below; there is no scalar copy of it to keep in step.)
 
 // ---- w = exp(0.5 log10 p) for N values at once, every stage applied to all N before the next one: N independent dependent
 // chains side by side, which is what fills the FP64 pipe at two waves per SIMD (the compiler keeps one evaluation's ~75
 // operations together if they are written one evaluation after the other), and each 64-bit constant is materialised once per
-// stage instead of once per evaluation.  log10 exactly as fig_log10_fast (same operations, same order, same bits); exp(x), x in
+// stage instead of once per evaluation.  log10 as described above; exp(x), x in
 // [-162, 0] or -inf: k = rint(x log2 e), r = x - k ln 2 as an exact high part and a small low part, exp(r) = 1 + r + r^2 q(r)
 // with the Taylor polynomial to r^13 (|r| <= 0.347: truncation 4e-18) and 1 + r_hi summed exactly, scaled by 2^k: 29 FP64
 // operations against the library's 43, max 0.69 ulp, equal to glibc's exp bit for bit on 98.4 % of the range (checked on the
@@ -143,6 +114,8 @@ typedef FigState __attribute__((address_space(3))) *fig_lsp;
 // ---- the indexed multiplies.  F0..F7 and the constant 1.0 are pinned to v[232:249]; p* are the products (any registers);
 // w* hold two 16-bit entries of the operand-select stream each: the value M0 takes (0x1000 = "SRC0 is indexed" | register
 // offset 2 * (4 * reverse + base), or 16 = the 1.0 for a slot without a regular read).  Per multiply ONE SALU instruction.
+// The blocks write M0 (and leave index mode off again): M0 is in their clobber lists so that the compiler neither keeps a value
+// of its own in M0 across them nor hoists an M0 initialisation past them.
 #define FIG_SH_M2(pa, pb, w) \
     "s_and_b32 m0, " w ", 0xffff\n v_mul_f64 " pa ", v[232:233], " pa "\n" \
     "s_lshr_b32 m0, " w ", 16\n v_mul_f64 " pb ", v[232:233], " pb "\n"
@@ -151,13 +124,13 @@ typedef FigState __attribute__((address_space(3))) *fig_lsp;
 FIG_FI void fig_sh_mul4(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]") "s_set_gpr_idx_off\n"
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
-                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]) : "scc");
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]) : "scc", "m0");
 }
 FIG_FI void fig_sh_mul8(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
                  FIG_SH_M2("%[p4]", "%[p5]", "%[w2]") FIG_SH_M2("%[p6]", "%[p7]", "%[w3]") "s_set_gpr_idx_off\n"
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7])
-                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]) : "scc");
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]) : "scc", "m0");
 }
 FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
@@ -166,7 +139,7 @@ FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t 
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]),
                    [p8] "+v"(p[8]), [p9] "+v"(p[9]), [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p15] "+v"(p[15])
                  : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]), [w4] "s"(w[4]), [w5] "s"(w[5]), [w6] "s"(w[6]), [w7] "s"(w[7])
-                 : "scc");
+                 : "scc", "m0");
 }
 
 // ---- the chain: NS products per lane over the L steps of the chunk.  colp = PQ + x (x = o + xoff: the lane's first column),

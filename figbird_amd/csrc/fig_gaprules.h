@@ -1,6 +1,6 @@
 // fig_gaprules.h -- per-gap rules of the reference that both the packer (fig_pack.h, inside libfighip.so) and the C++
-// host (figbird_amd/csrc/host) need: the candidate range of a gap and the one piece of state the reference carries from
-// gap to gap inside a worker process.  Pure C++, no device or host-library dependencies.
+// host (figbird_amd/csrc/host) need: the candidate range of a gap and the carry rule of the one piece of state the
+// reference hands from gap to gap inside a worker process.  Pure C++, no device or host-library dependencies.
 #ifndef FIG_GAPRULES_H
 #define FIG_GAPRULES_H
 #include <algorithm>
@@ -33,21 +33,15 @@ static int gap_range(int G0, float f1, float f2) {
 }
 
 // The reference's `overlap_threshold` is a file-level global of Figbird.cpp (:103), 0 when a worker process starts and set
-// to 5 the first time a candidate loop gets to :6317; every later gap OF THAT PROCESS sees 5 from its first line on.  A
-// loop gets there unless its first initialize() leaves side_limit < 10 (:6303; follows from the gap's distance to the
-// contig ends, initialize_start_end :2269-2296) or closes the gap by a negative overlap (:6306; only the fill knows -- such
-// a gap is taken as having got there, the one approximation in this rule).
-static inline bool fig_gap_sets_overlap_threshold(const fig_model *m, int64_t gapStart, int64_t contigLen, int G0, int fillflag) {
-    int alloc_arg, lgf; float f1, f2;
-    gap_alloc(m, G0, &alloc_arg, &f1, &f2, &lgf);
-    int64_t sl = 30;
-    const int gmin = fillflag == -1 ? G0 : (int)(G0 * f1);
-    const int Gs[2] = {G0, gmin};
-    for (int G : Gs) {
-        if (gapStart - m->max_distance < 0) sl = std::min<int64_t>(sl, gapStart);
-        if (gapStart + G + m->max_distance > contigLen) sl = std::min<int64_t>(sl, contigLen - (gapStart + G));
-    }
-    return sl >= 10;
+// to 5 the first time a candidate loop of that process gets to :6317; every later gap OF THAT PROCESS sees 5 from its first
+// line on.  Whether a gap's loop gets there is measured on the device (`reach`, fig_engine_sched.h: fig_gap_probe -- it
+// depends on the gap's reads: a gap that closes by a negative overlap at its first candidate leaves the loop before that
+// line); the carry is the prefix-OR of those bits along the process's gap list (ascending gap ids, Figbird.cpp:7277-7317).
+// `process`: gap ids in the order the process takes them; reach/preset are indexed by gap id.
+template <class IdList>
+static inline void fig_ot_carry(const IdList &process, const uint8_t *reach, uint8_t *preset) {
+    bool reached = false;
+    for (auto g : process) { preset[(size_t)g] = reached ? 1 : 0; if (reach[(size_t)g]) reached = true; }
 }
 
 #endif

@@ -75,6 +75,8 @@ struct FigPacked {
     std::vector<int32_t> u_pos, u_aux, u_len, p_pos, p_aux, p_clip, p_ref, p_len;
     std::vector<int64_t> u_woff, p_woff, p_qoff, str_off;
     std::vector<FigLaunchClass> classes;
+    std::vector<uint8_t> ot_preset;   // per gap: overlap_threshold already set by an earlier gap of its worker process (fig_gap_batch::gap_ot_preset)
+    bool ot_given = false;            // the caller supplied it; otherwise the library measures it (one process, batch order)
     int capR = 1, capP = 1, capC = 1, capG = 8, capW = 0, capE = 0;
     int64_t str_total = 0, n_gaps = 0, persist_total = 0, stream_total = 0;   // stream_total: dwords of the operand-select stream
     int nslots = 64;                  // speculative candidate slots per gap (fig_engine_sched.h)
@@ -184,16 +186,13 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         K.stream_total = so + FIG_SH_C;        // + one padded step: the chain prefetches the row after the last one
     }
     K.capG = (K.capG + 7) & ~7;
-    {   // which gaps find the reference's process-level overlap_threshold already at 5 (fig_gaprules.h): given by the caller
-        // (gap_ot_preset: it knows which worker process of the reference a gap would run in, and which gaps of that process
-        // are in other shards), else derived here for ONE process taking the gaps in batch order (numthreads = 1)
-        bool reached = false;
-        for (int64_t g = 0; g < ng; g++) {
-            FigDevGap &d = K.gaps[g];
-            if (b->gap_ot_preset) { d.pad = b->gap_ot_preset[g] ? 1 : 0; continue; }
-            d.pad = reached ? 1 : 0;
-            if (fig_gap_sets_overlap_threshold(m, d.gapStart, d.contigLen, d.G0, d.fillflag)) reached = true;
-        }
+    {   // which gaps find the reference's process-level overlap_threshold already at 5 (Figbird.cpp:103, :6317): given by the
+        // caller (gap_ot_preset: it knows which worker process of the reference a gap would run in, and which gaps of that
+        // process are in other shards), else MEASURED by the library after the upload (fig_abi.hip: probe_and_preset) for ONE
+        // process taking the gaps in batch order (numthreads = 1)
+        K.ot_given = b->gap_ot_preset != nullptr;
+        K.ot_preset.assign((size_t)std::max<int64_t>(ng, 1), 0);
+        for (int64_t g = 0; g < ng; g++) { K.gaps[g].pad = 0; if (b->gap_ot_preset) K.ot_preset[(size_t)g] = b->gap_ot_preset[g] ? 1 : 0; }
     }
     // ---- launch classes by the longest candidate a gap can reach (LDS columns); within a class the most
     // expensive gaps come first.  gmax: candidate range (:6237-6238), checkGapReads probes (:6121-6153).
@@ -277,8 +276,10 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             K.classes.push_back(c);
         }
         K.capE = std::max(K.capE, c.ncolE);
+        // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
         K.capW = std::max(K.capW, (c.tiles ? 8 : c.nteams) * c.Wcap + 1024);
-        if (m->unmapped_flag && c.lds_tab && !c.tiles && c.nteams >= 4) K.capW = std::max(K.capW, (getenv("FIG_CAPW_SCALE") ? atoi(getenv("FIG_CAPW_SCALE")) : 1) * FIG_SH_SC * FIG_SH_C * c.Wcap + 1024);   // product rows of the shared-factor E-step (fig_engine_shared.h)   // + slack: the column pass reads up to 2 tiles past a row's end (tiled class: the MLE pass keeps its buffers in the HBM rows)
+        // product rows of the shared-factor E-step (fig_engine_shared.h): one super-chunk of reads x all placements
+        if (m->unmapped_flag && c.lds_tab && !c.tiles && c.nteams >= 4) K.capW = std::max(K.capW, FIG_SH_SC * FIG_SH_C * c.Wcap + 1024);
     }
     return FIG_OK;
 }

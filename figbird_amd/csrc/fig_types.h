@@ -47,7 +47,7 @@ struct FigDevGap {
     int64_t strOff;                  // offset of this gap's result string
     int32_t gapNo; int32_t cls;
     int64_t persistOff;              // this gap's persistent slab (candidate-parallel mode)
-    int32_t capGg, rangeCap, nslots, pad;
+    int32_t capGg, rangeCap, nslots, pad;   // (pad: unused)
     int64_t streamOff;               // first dword of this gap's operand-select stream (FigDevBatch::ustream)
 };
 
@@ -83,7 +83,8 @@ struct FigDevBatch {
     int32_t capG, capR, capP, capC;  // capacities the slab was carved for (columns, unmapped reads, partial reads, candidates)
     int32_t capW, capE;              // weight-buffer doubles, extended-table columns
     uint8_t *persist;                // per-gap persistent slabs
-    int32_t *gapctl;                 // [n_gaps*4] {status (0 finished, 1 more candidates, 2 loop done), next j, range, -}
+    int32_t *gapctl;                 // [n_gaps*4] {status (0 finished, 1 more candidates, 2 loop done), next j, range, reach bit of fig_probe_kernel}
+    const uint8_t *ot_preset;        // [n_gaps] 1 = the gap's worker process has set overlap_threshold before it gets to the gap (Figbird.cpp:103, :6317)
 };
 
 #endif

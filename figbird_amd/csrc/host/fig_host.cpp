@@ -681,20 +681,16 @@ std::vector<std::vector<int32_t>> thread_allocation(const std::vector<int32_t> &
     return T;
 }
 
-void assign_processes(const RunArgs &a, const Scaffold &sc, Batch &B) {
-    const size_t ng = B.gap_contig.size();
+void assign_processes(const RunArgs &a, const Scaffold &, Batch &B) {
     B.processes = thread_allocation(B.gap_len, a.num_threads, a.unm_limit);
-    B.gap_ot_preset.assign(ng, 0);
-    fig_model m; memset(&m, 0, sizeof(m));                        // the rule reads run parameters only
-    m.partial_flag = a.partial_flag; m.unmapped_flag = a.unmapped; m.partial_len = a.partial_len; m.unm_limit = a.unm_limit; m.max_distance = a.D;
-    for (const auto &p : B.processes) {
-        bool reached = false;
-        for (int32_t g : p) {
-            B.gap_ot_preset[(size_t)g] = reached ? 1 : 0;
-            const int c = B.gap_contig[(size_t)g];
-            if (fig_gap_sets_overlap_threshold(&m, B.gap_start[(size_t)g], sc.off[(size_t)c + 1] - sc.off[(size_t)c], B.gap_len[(size_t)g], B.gap_fillflag[(size_t)g])) reached = true;
-        }
-    }
+    B.gap_ot_preset.assign(B.gap_contig.size(), 0);               // until measured: ot_presets_from_reach
+}
+
+// The carry of the reference's process-global overlap_threshold (Figbird.cpp:103, :6317) from the measured bits
+// (fig_batch_probe_reach: reach[g] = the candidate loop of gap g gets to :6317): along each worker process's gap list.
+void ot_presets_from_reach(Batch &B, const uint8_t *reach) {
+    B.gap_ot_preset.assign(B.gap_contig.size(), 0);
+    for (const auto &p : B.processes) fig_ot_carry(p, reach, B.gap_ot_preset.data());
 }
 
 bool write_gaploads(const RunArgs &a, const Batch &b, std::string &err) {
@@ -958,6 +954,15 @@ extern "C" int fighost_run_params(void *h, int32_t *out6) {        // read lengt
 }
 extern "C" const char *fighost_run_message(void *h, int i) { return ((Run *)h)->B.messages[(size_t)i].c_str(); }
 extern "C" int fighost_run_model(void *h, fig_model *out) { Run *r = (Run *)h; r->M.fill(*out, r->a); return 0; }
+
+// reach[g] for every gap of the run (global gap ids; figfill_mp all-gathers the shards' fig_batch_probe_reach bits) ->
+// preset[g] = the gap's worker process of the reference has set overlap_threshold before it gets to the gap.
+extern "C" int fighost_run_ot_presets(void *h, const uint8_t *reach, uint8_t *preset) {
+    Run *r = (Run *)h;
+    fighost::ot_presets_from_reach(r->B, reach);
+    for (size_t g = 0; g < r->B.gap_ot_preset.size(); g++) preset[g] = r->B.gap_ot_preset[g];
+    return 0;
+}
 
 // Sub-batch of the gaps `ids` (any order; kept in that order), owned by the handle until the next call.
 extern "C" int fighost_run_shard(void *h, const int64_t *ids, int64_t n, fig_gap_batch *out, int64_t *n_ureads, int64_t *n_preads) {

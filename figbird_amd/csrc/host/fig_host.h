@@ -48,7 +48,7 @@ struct Batch {                      // owns the arrays fig_gap_batch points into
     std::string u_seq, p_seq, p_qual;
     std::vector<std::string> messages;      // stdout lines the reference prints while parsing
     // the reference's worker processes (assign_processes): gap ids per process in the order it fills them, and per gap
-    // whether its process has set overlap_threshold before it gets there (fig_gap_batch::gap_ot_preset)
+    // whether its process has set overlap_threshold before it gets there (fig_gap_batch::gap_ot_preset; measured, see below)
     std::vector<std::vector<int32_t>> processes;
     std::vector<uint8_t> gap_ot_preset;
     void view(fig_gap_batch &b, const Scaffold &sc) const;
@@ -58,8 +58,10 @@ struct Batch {                      // owns the arrays fig_gap_batch points into
 // a process.  (Gaps of at most `gapthresh` = 400 bp are dealt round-robin, the longer ones fill the processes up in the
 // order of their remaining capacity.)
 std::vector<std::vector<int32_t>> thread_allocation(const std::vector<int32_t> &gap_len, int num_threads, int gapthresh = 400);
-// Fills B.processes / B.gap_ot_preset for the run `a` (needs only the run parameters, not the model tables).
+// Fills B.processes for the run `a` (needs only the run parameters, not the model tables); B.gap_ot_preset is all 0 until
+// ot_presets_from_reach() has the measured bits (fig_batch_probe_reach, include/figbird_hip.h), indexed by gap id.
 void assign_processes(const RunArgs &a, const Scaffold &sc, Batch &B);
+void ot_presets_from_reach(Batch &B, const uint8_t *reach);
 // gaploads.txt as the reference leaves it in Temp/ (one line of tab-terminated gap ids per process)
 bool write_gaploads(const RunArgs &a, const Batch &b, std::string &err);
 

@@ -26,18 +26,34 @@ static int fail(const std::string &m) { fprintf(stderr, "%s\n", m.c_str()); retu
 // FillGaps.cpp:456-649), one host thread per GPU creates its own fig_ctx (contexts are independent, include/figbird_hip.h)
 // and fills its shard through fig_fill_gaps with no exchange on the data path; the shard results meet in host memory in
 // global gap / read order, so the writers below see exactly what a single-GPU run hands them.
-struct ShardRun { std::vector<int64_t> ids; Batch sub; Results R; fig_stats st; int rc = 0; std::string err; };
+struct ShardRun { std::vector<int64_t> ids; Batch sub; Results R; fig_stats st; int rc = 0; std::string err; fig_ctx *ctx = nullptr; std::vector<uint8_t> reach, preset; };
 
-static void run_shard(int device, const fig_model *fm, const Scaffold *sc, ShardRun *S) {
+static void shard_fail(ShardRun *S, int rc, const std::string &what) {
+    S->rc = rc; S->err = what + ": " + fig_strerror(rc);
+    if (S->ctx) { fig_ctx_destroy(S->ctx); S->ctx = nullptr; }
+}
+
+// phase 1: context, model, upload, and which of the shard's gaps get to Figbird.cpp:6317 (fig_batch_probe_reach)
+static void shard_open(int device, const fig_model *fm, const Scaffold *sc, ShardRun *S) {
     memset(&S->st, 0, sizeof(S->st));
     fig_gap_batch fb; S->sub.view(fb, *sc);
     const int64_t ng = fb.n_gaps;
+    S->reach.assign((size_t)std::max<int64_t>(ng, 1), 0);
     if (ng == 0) return;
-    fig_ctx *ctx = nullptr;
-    int rc = fig_ctx_create(device, &ctx);
-    if (rc) { S->rc = rc; S->err = std::string("fig_ctx_create(") + std::to_string(device) + "): " + fig_strerror(rc); return; }
-    rc = fig_ctx_set_model(ctx, fm);
-    if (rc) { fig_ctx_destroy(ctx); S->rc = rc; S->err = std::string("fig_ctx_set_model: ") + fig_strerror(rc); return; }
+    int rc = fig_ctx_create(device, &S->ctx);
+    if (rc) { S->ctx = nullptr; return shard_fail(S, rc, std::string("fig_ctx_create(") + std::to_string(device) + ")"); }
+    if ((rc = fig_ctx_set_model(S->ctx, fm))) return shard_fail(S, rc, "fig_ctx_set_model");
+    if ((rc = fig_batch_upload(S->ctx, &fb))) return shard_fail(S, rc, std::string("fig_batch_upload on device ") + std::to_string(device));
+    if ((rc = fig_batch_probe_reach(S->ctx, S->reach.data()))) return shard_fail(S, rc, "fig_batch_probe_reach");
+}
+
+// phase 2: the carry worked out over ALL shards (S->preset, shard order), then the fill
+static void shard_fill(int device, const fig_model *fm, const Scaffold *sc, ShardRun *S) {
+    fig_gap_batch fb; S->sub.view(fb, *sc);
+    const int64_t ng = fb.n_gaps;
+    if (ng == 0 || !S->ctx) return;
+    int rc = fig_batch_set_ot_preset(S->ctx, S->preset.data());
+    if (rc) return shard_fail(S, rc, "fig_batch_set_ot_preset");
     Results &R = S->R;
     const int64_t cap = fig_results_capacity(fm, &fb);
     R.filled_len.assign(ng, 0); R.gaptofill.assign(ng, 0); R.str_off.assign(ng + 1, 0); R.str.assign((size_t)std::max<int64_t>(cap, 1), 'N');
@@ -47,28 +63,38 @@ static void run_shard(int device, const fig_model *fm, const Scaffold *sc, Shard
     fr.filled_len = R.filled_len.data(); fr.gaptofill = R.gaptofill.data(); fr.str_off = R.str_off.data();
     fr.str = &R.str[0]; fr.str_capacity = (int64_t)R.str.size();
     fr.draw_pos = R.draw_pos.data(); fr.draw_isz = R.draw_isz.data(); fr.draw_len = R.draw_len.data();
-    rc = fig_fill_gaps(ctx, &fb, &fr);
-    fig_get_stats(ctx, &S->st);
-    fig_ctx_destroy(ctx);
-    if (rc) { S->rc = rc; S->err = std::string("fig_fill_gaps on device ") + std::to_string(device) + ": " + fig_strerror(rc); }
+    rc = fig_fill_resident(S->ctx, &fr);
+    fig_get_stats(S->ctx, &S->st);
+    if (rc) return shard_fail(S, rc, std::string("fig_fill_resident on device ") + std::to_string(device));
+    fig_ctx_destroy(S->ctx); S->ctx = nullptr;
 }
 
 // Fill B over `devices`; on success R holds the whole gap set in global order.  Returns 0 or 1 (message in err).
-static int fill_multi(const std::vector<int> &devices, const RunArgs &a, const Scaffold &sc, const Batch &B, const fig_model &fm, Results &R,
+static int fill_multi(const std::vector<int> &devices, const RunArgs &a, const Scaffold &sc, Batch &B, const fig_model &fm, Results &R,
                       fig_stats &st, std::string &err) {
     const int world = (int)devices.size();
     const int64_t ng = (int64_t)B.gap_contig.size();
     std::vector<std::vector<int64_t>> shards = partition_lpt(estimate_cost(B, a, fm.max_read_length), world);
     std::vector<ShardRun> runs((size_t)world);
     for (int r = 0; r < world; r++) { runs[r].ids = shards[r]; make_shard(B, shards[r], runs[r].sub); }
-    if (getenv("FIGFILL_SERIAL")) {                      // test knob: one shard after the other (the CPU emulation library keeps global state)
-        for (int r = 0; r < world; r++) run_shard(devices[r], &fm, &sc, &runs[r]);
-    } else {
+    const bool serial = getenv("FIGFILL_SERIAL") != nullptr;   // test knob: one shard after the other (the CPU emulation library keeps global state)
+    auto phase = [&](void (*fn)(int, const fig_model *, const Scaffold *, ShardRun *)) {
+        if (serial) { for (int r = 0; r < world; r++) fn(devices[r], &fm, &sc, &runs[r]); return; }
         std::vector<std::thread> th;
-        for (int r = 0; r < world; r++) th.emplace_back(run_shard, devices[r], &fm, &sc, &runs[r]);
+        for (int r = 0; r < world; r++) th.emplace_back(fn, devices[r], &fm, &sc, &runs[r]);
         for (auto &t : th) t.join();
+    };
+    auto failed = [&]() { for (int r = 0; r < world; r++) if (runs[r].rc) { err = "figfill: " + runs[r].err; for (auto &q : runs) if (q.ctx) { fig_ctx_destroy(q.ctx); q.ctx = nullptr; } return true; } return false; };
+    phase(shard_open);
+    if (failed()) return 1;
+    {   // the one exchange before the fill: every shard's reach bits, carried along the reference's worker processes
+        std::vector<uint8_t> reach((size_t)std::max<int64_t>(ng, 1), 0);
+        for (int r = 0; r < world; r++) for (size_t k = 0; k < runs[r].ids.size(); k++) reach[(size_t)runs[r].ids[k]] = runs[r].reach[k];
+        ot_presets_from_reach(B, reach.data());
+        for (int r = 0; r < world; r++) { runs[r].preset.assign(std::max<size_t>(runs[r].ids.size(), 1), 0); for (size_t k = 0; k < runs[r].ids.size(); k++) runs[r].preset[k] = B.gap_ot_preset[(size_t)runs[r].ids[k]]; }
     }
-    for (int r = 0; r < world; r++) if (runs[r].rc) { err = "figfill: " + runs[r].err; return 1; }
+    phase(shard_fill);
+    if (failed()) return 1;
     // ---- merge in global gap order (strings compacted as fig_fill_gaps leaves them) and global read order
     const int64_t NU = (int64_t)B.u_anchor_pos.size(), NP = (int64_t)B.p_pos.size();
     R.filled_len.assign(ng, 0); R.gaptofill.assign(ng, 0); R.str_off.assign(ng + 1, 0);
@@ -113,9 +139,18 @@ int main(int argc, char **argv) {
     int device = dev_env ? atoi(dev_env) : 0;
     std::vector<int> devices;                            // FIGFILL_DEVICES=0,1,...,7: one shard, host thread and fig_ctx per listed GPU
     if (const char *dl = getenv("FIGFILL_DEVICES")) {
-        for (const char *q = dl; *q;) { char *e; long v = strtol(q, &e, 10); if (e == q) break; devices.push_back((int)v); q = *e == ',' ? e + 1 : e; if (*e != ',' ) break; }
+        const char *q = dl;
+        while (true) {
+            char *e; long v = strtol(q, &e, 10);
+            if (e == q || v < 0) { devices.clear(); break; }
+            devices.push_back((int)v);
+            if (*e == 0) break;
+            if (*e != ',') { devices.clear(); break; }           // trailing garbage ("0,1x") is an error, not a shorter list
+            q = e + 1;
+        }
         if (devices.empty()) return fail("figfill: FIGFILL_DEVICES must be a comma-separated list of GPU ordinals");
     }
+    setenv("GPU_MAX_HW_QUEUES", "8", 0);                 // one hardware queue per scheduler lane; before any thread or HIP call (fig_abi.hip: fig_ctx_create)
     auto t0 = std::chrono::steady_clock::now();
 
     std::string err;
@@ -188,10 +223,18 @@ int main(int argc, char **argv) {
         dn.assign((size_t)std::max<int64_t>(ng, 1), 0); di.assign((size_t)std::max<int64_t>(ng, 1) * maxc * 3, 0); dl.assign((size_t)std::max<int64_t>(ng, 1) * maxc, 0);
         fr.dbg_max_cand = maxc; fr.dbg_n_cand = dn.data(); fr.dbg_cand_i = di.data(); fr.dbg_cand_lik = dl.data();
     }
-    rc = fig_fill_gaps(ctx, &fb, &fr);
+    // upload; measure which gaps get to Figbird.cpp:6317; carry that along the reference's $num_threads worker processes
+    // (overlap_threshold, :103); fill
+    rc = fig_batch_upload(ctx, &fb);
+    if (!rc && ng > 0) {
+        std::vector<uint8_t> reach((size_t)ng, 0);
+        rc = fig_batch_probe_reach(ctx, reach.data());
+        if (!rc) { ot_presets_from_reach(B, reach.data()); rc = fig_batch_set_ot_preset(ctx, B.gap_ot_preset.data()); }
+    }
+    if (!rc) rc = fig_fill_resident(ctx, &fr);
     fig_stats st; memset(&st, 0, sizeof(st)); fig_get_stats(ctx, &st);
     fig_ctx_destroy(ctx);
-    if (rc) return fail(std::string("figfill: fig_fill_gaps: ") + fig_strerror(rc));
+    if (rc) return fail(std::string("figfill: fill: ") + fig_strerror(rc));
 
     if (!write_gapout(a, B, R, err)) return fail(err);
     if (!write_draw(a, B, R, err)) return fail(err);

@@ -54,6 +54,22 @@ def all_status_max(code: int, device=None) -> int:
     return int(t.item())
 
 
+def all_reduce_or_bits(bits: np.ndarray, device=None) -> np.ndarray:
+    """OR over ranks of a small per-gap bit array (each rank sets the bits of its own shard): the one exchange BEFORE the
+    fill -- which gaps get to Figbird.cpp:6317 (fig_batch_probe_reach), needed because the gap that sets the reference's
+    process-global overlap_threshold may sit on another rank than the gap that reads it."""
+    import torch
+    import torch.distributed as dist
+    a = np.ascontiguousarray(bits, dtype=np.int32)
+    if not dist.is_initialized() or dist.get_world_size() == 1 or len(a) == 0:
+        return (a != 0).astype(np.uint8)
+    t = torch.from_numpy(a.copy())
+    if device is not None:
+        t = t.to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return (t.cpu().numpy() != 0).astype(np.uint8)
+
+
 def all_gather_packed(ids: Sequence[int], res, n_total: int, device=None, extras: Sequence[np.ndarray] = (), force_collective: bool = False):
     """All-gather the shard results as packed byte buffers: one small header exchange, then ONE all-gather of a
     single uint8 buffer per rank laid out [ids | filled_len | gaptofill | extras... | gap strings], straight from the

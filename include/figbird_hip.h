@@ -95,8 +95,12 @@ typedef struct fig_gap_batch {
     /* state the reference carries from gap to gap inside ONE worker process (FillGaps.cpp:456-649 deals the gaps to
      * $num_threads processes, each running Figbird.cpp main over its list in ascending gap order): [n_gaps] 1 when that
      * process has already set its global overlap_threshold (Figbird.cpp:103, :6317) by the time it gets to the gap.
-     * NULL = the batch is one process taking the gaps in batch order (numthreads = 1).  A caller that fills a SHARD
-     * of a run must pass it, because the gap that set the value may be in another shard (fig_host.cpp: assign_processes). */
+     * NULL = the batch is one process taking the gaps in batch order (numthreads = 1): the library measures the carry
+     * itself at upload.  A caller that deals the gaps to several processes, or fills a SHARD of a run (the gap that
+     * set the value may be in another shard), uploads, asks fig_batch_probe_reach() which gaps get to :6317, carries
+     * the bits along each process's gap list and hands the result to fig_batch_set_ot_preset() before the fill
+     * (figfill: fig_host.cpp ot_presets_from_reach).  Only read in partial mode (the reference never reads the
+     * global in an unmapped-mode run). */
     const uint8_t *gap_ot_preset;
 } fig_gap_batch;
 
@@ -163,6 +167,15 @@ int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *batch);
 int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out);
 void fig_batch_free(fig_ctx *ctx);
 int fig_fill_gaps(fig_ctx *ctx, const fig_gap_batch *batch, fig_gap_results *out);
+
+/* The exact carry of Figbird.cpp's process-global overlap_threshold (:103, :6298-6317; read at :2684, :2760-2766).
+ * fig_batch_probe_reach: reach[g] = 1 iff the candidate loop of gap g of the RESIDENT batch gets to :6317 -- it does
+ * unless the loop has no candidate, or its first initialize() leaves side_limit < 10 (:6303), or the gap closes by a
+ * negative overlap at its first candidate (:6305-6306); measured on the device before any gap is filled (none of it
+ * depends on the threshold).  Unmapped-mode runs never read the global: reach is all 0 there and nothing is launched.
+ * fig_batch_set_ot_preset: replaces gap_ot_preset of the resident batch ([n_gaps], batch order). */
+int fig_batch_probe_reach(fig_ctx *ctx, uint8_t *reach);
+int fig_batch_set_ot_preset(fig_ctx *ctx, const uint8_t *preset);
 
 int fig_get_stats(const fig_ctx *ctx, fig_stats *out);
 

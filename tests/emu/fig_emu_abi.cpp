@@ -86,11 +86,42 @@ extern "C" int fig_batch_upload(fig_ctx *ctx, const fig_gap_batch *b) {
     int rc = fig_pack(&ctx->hm, b, sizeof(FigState), ctx->K);
     if (rc) return rc;
     ctx->have_batch = true;
+    const int64_t ng = ctx->K.n_gaps;
+    if (!ctx->K.ot_given && ctx->hm.partial_flag && ng > 0) {      // as fig_abi.hip: one process in batch order, carry measured
+        std::vector<uint8_t> reach((size_t)ng, 0), preset((size_t)ng, 0);
+        if ((rc = fig_batch_probe_reach(ctx, reach.data()))) return rc;
+        std::vector<int64_t> ids((size_t)ng);
+        for (int64_t g = 0; g < ng; g++) ids[(size_t)g] = g;
+        fig_ot_carry(ids, reach.data(), preset.data());
+        if ((rc = fig_batch_set_ot_preset(ctx, preset.data()))) return rc;
+    }
     return FIG_OK;
 }
 
+static int emu_run(fig_ctx *ctx, fig_gap_results *out, uint8_t *probe_reach);
+
 extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     if (!ctx || !out || !ctx->have_batch) return FIG_EINVAL;
+    return emu_run(ctx, out, nullptr);
+}
+
+// fig_batch_probe_reach / fig_batch_set_ot_preset as in fig_abi.hip
+extern "C" int fig_batch_probe_reach(fig_ctx *ctx, uint8_t *reach) {
+    if (!ctx || !reach || !ctx->have_batch) return FIG_EINVAL;
+    memset(reach, 0, (size_t)ctx->K.n_gaps);
+    if (!ctx->hm.partial_flag || ctx->K.n_gaps == 0) return FIG_OK;
+    return emu_run(ctx, nullptr, reach);
+}
+extern "C" int fig_batch_set_ot_preset(fig_ctx *ctx, const uint8_t *preset) {
+    if (!ctx || !preset || !ctx->have_batch) return FIG_EINVAL;
+    for (int64_t g = 0; g < ctx->K.n_gaps; g++) ctx->K.ot_preset[(size_t)g] = preset[g] ? 1 : 0;
+    return FIG_OK;
+}
+
+// out != nullptr: the fill; probe_reach != nullptr: the reach pre-pass (fig_probe_kernel's role)
+static int emu_run(fig_ctx *ctx, fig_gap_results *out, uint8_t *probe_reach) {
+    fig_gap_results none; memset(&none, 0, sizeof(none));
+    if (!out) out = &none;
     FigPacked &K = ctx->K;
     int64_t ng = K.n_gaps;
     FigDevBatch B; memset(&B, 0, sizeof(B));
@@ -121,6 +152,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
     B.persist = persist.data();
     std::vector<int32_t> gapctl((size_t)ng * 4 + 4, 0);
     B.gapctl = gapctl.data();
+    B.ot_preset = K.ot_preset.data();
     const FigDevModel &M = ctx->dm;
     for (const FigLaunchClass &c : K.classes) {
         // one emulated lane = one wave of width 1; the class's team count is kept so the chunking logic runs
@@ -158,7 +190,14 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         const char *sched = getenv("FIG_SCHED");
         const bool seq = sched && strcmp(sched, "seq") == 0;
         auto persist_of = [&](const FigDevGap &g, FigPersist &P) { fig_persist_layout(B.persist + g.persistOff, g.capGg, g.nU, g.nP, g.rangeCap, g.nslots, sizeof(FigState), &P); };
-        if (seq) {
+        if (probe_reach) {
+            for (int qi = c.q_begin; qi < c.q_end; qi++) {
+                E.g = &K.gaps[K.order[qi]];
+                FigPersist P; persist_of(*E.g, P);
+                fig_bind(E, work, P, FIG_BIND_SEQ, 0, E.g->capGg);
+                probe_reach[K.order[qi]] = fig_gap_probe<true>(E) ? 1 : 0;
+            }
+        } else if (seq) {
             for (int qi = c.q_begin; qi < c.q_end; qi++) {
                 E.g = &K.gaps[K.order[qi]];
                 FigPersist P; persist_of(*E.g, P);
@@ -211,6 +250,7 @@ extern "C" int fig_fill_resident(fig_ctx *ctx, fig_gap_results *out) {
         }
         counters[1] += E.flops; counters[3] += E.mle_alg; counters[4] += E.mle_exec;
     }
+    if (probe_reach) return FIG_OK;
     ctx->stats.place_calls = (int64_t)counters[0]; ctx->stats.alg_flops = (double)counters[1];
     ctx->stats.spec_flops = (double)counters[1]; ctx->stats.mle_alg_flops = (double)counters[3]; ctx->stats.mle_exec_flops = (double)counters[4];
     ctx->stats.packed_bytes = K.packed_bytes(); ctx->stats.n_launches = (int)K.classes.size();

@@ -173,3 +173,89 @@ def test_gap_deal_matches_live_reference(lens, threads, tmp_path):
         outs[tag] = {fn: util.read(p["tmp"] + fn) for fn in ("gaploads.txt", "draw.txt", "gapout.txt", "filledContigs.fa")}
     assert outs["host"] == outs["ref"]
     assert outs["oracle"] == outs["ref"]
+
+
+def _run_handle(root):
+    import ctypes as C
+    from figbird_amd import api
+    h = api.load_host_library()
+    argv = util.meta(root)["fillgaps_argv"]
+    hh = h.fighost_run_open((C.c_char_p * 15)(*[a.encode() for a in argv]), C.create_string_buffer(256), 256)
+    assert hh
+    return h, hh
+
+
+def _reach_and_presets(root, lib_path):
+    """(reach bits measured by the library, presets carried along the reference's worker processes) of a golden's run."""
+    import ctypes as C
+    from figbird_amd import api
+    cwd = os.getcwd(); os.chdir(root)
+    try:
+        h, hh = _run_handle(root)
+        n = int(h.fighost_run_ngaps(hh))
+        ids = np.arange(n, dtype=np.int64)
+        cm = api.FigModel(); h.fighost_run_model(hh, C.byref(cm))
+        cb = api.FigGapBatch(); su = C.c_int64(); sp = C.c_int64()
+        assert h.fighost_run_shard(hh, api._p(ids, api.c_i64_p), n, C.byref(cb), C.byref(su), C.byref(sp)) == 0
+        eng = api.Engine(0, lib_path=lib_path)
+        eng.set_model_struct(cm)
+        eng.upload_struct(cb)
+        reach = eng.probe_reach().copy()
+        eng.free_batch(); eng.close()
+        preset = np.zeros(n, dtype=np.uint8)
+        h.fighost_run_ot_presets(hh, api._p(reach, api.c_u8_p), api._p(preset, api.c_u8_p))
+        h.fighost_run_close(hh)
+    finally:
+        os.chdir(cwd)
+    return reach.tolist(), preset.tolist()
+
+
+OT_EXPECT = {   # golden -> (reach, presets): tools/make_golden.py explains the two fixtures
+    # gap 0 closes by a negative overlap at its first candidate, gap 1 sits 8 bp from the contig end: neither gets to :6317,
+    # so gap 1 still sees overlap_threshold = 0 (a carry predicted from contig geometry alone handed it 5)
+    "ot_carry": ([0, 0], [0, 0]),
+    # $num_threads = 3: processes {0, 3}, {1}, {2}: gap 3 follows gap 0 in ITS process, although gaps 1 and 2 got there
+    "ot_carry_t3": ([0, 1, 1, 0], [0, 0, 0, 0]),
+    "threads3": ([1] * 8, [0, 0, 0, 1, 1, 1, 1, 1]),
+    "neg_overlap": ([1, 0], [0, 1]),
+}
+
+
+@pytest.mark.parametrize("name", sorted(OT_EXPECT))
+def test_overlap_threshold_carry_is_measured(name, tmp_path):
+    """Figbird.cpp:103, :6298-6317: the library measures which gaps get to `overlap_threshold=5` (fig_batch_probe_reach; here the
+    one-lane emulation of the same device code), the host carries the bits along the reference's worker processes."""
+    root = util.extract_golden(name, str(tmp_path))
+    assert _reach_and_presets(root, util.EMULIB) == OT_EXPECT[name]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(OT_EXPECT))
+def test_overlap_threshold_carry_is_measured_on_the_device(name, tmp_path):
+    """The same through libfighip.so: fig_probe_kernel on the MI355X."""
+    root = util.extract_golden(name, str(tmp_path))
+    assert _reach_and_presets(root, None) == OT_EXPECT[name]
+    assert "libfighip.so" in open("/proc/self/maps").read()
+
+
+def test_library_measures_the_carry_itself_without_a_preset(tmp_path):
+    """gap_ot_preset = NULL: one worker process in batch order, carry measured by the library at upload -- same strings as with
+    the explicit carry, and (on `ot_carry`) the preset differs from what contig geometry alone would have predicted."""
+    from tools import make_golden
+    case = make_golden.make("ot_carry")
+    root = util.extract_golden("ot_carry", str(tmp_path))
+    cwd = os.getcwd(); os.chdir(root)
+    try:
+        model = api.model_from_files("scf.fa", "tmp/", "tmp/myout.sam", partial_flag=1, unmapped_flag=0, script_itr=1, max_distance=case.max_distance,
+                                     read_length=case.read_len, neg_overlap=case.neg_overlap, partial_len=case.partial_len)
+    finally:
+        os.chdir(cwd)
+    exp = [ln.split("\t") for ln in util.read(os.path.join(root, "ref", "gapout.txt")).splitlines()]
+    outs = []
+    for preset in (None, np.zeros(2, dtype=np.uint8)):
+        b = synth.case_to_batch(case); b.gap_ot_preset = preset
+        eng = api.Engine(0, lib_path=util.EMULIB); eng.set_model(model)
+        res = eng.fill(b); eng.close()
+        outs.append((res.filled_len.tolist(), res.gaptofill.tolist(), res.strings))
+    assert outs[0] == outs[1]
+    assert outs[0][0] == [int(e[4]) for e in exp] and outs[0][2] == [e[5] if len(e) > 5 else "" for e in exp]

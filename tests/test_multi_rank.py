@@ -78,7 +78,7 @@ def _mp_worker(rank, world, port, root, name, q, lib=util.EMULIB):
     q.put((rank, rc))
 
 
-@pytest.mark.parametrize("name,world", [("unmapped_mid_err", 2), ("partial_brackets", 2), ("edge_contig_ends", 3), ("threads3", 2)])
+@pytest.mark.parametrize("name,world", [("unmapped_mid_err", 2), ("partial_brackets", 2), ("edge_contig_ends", 3), ("threads3", 2), ("ot_carry", 2), ("ot_carry_t3", 2)])
 def test_figfill_mp_writes_the_reference_files(name, world, tmp_path):
     """The multi-GPU product path (figbird_amd.figfill_mp: run handle -> LPT shards -> C ABI -> one packed all-gather ->
     rank 0 writes) on `world` gloo ranks: gapout.txt, draw.txt, filledContigs.fa and Ncount.txt byte-identical to the
@@ -127,16 +127,18 @@ def test_figfill_mp_on_the_device_single_rank(tmp_path, monkeypatch):
 
 
 @pytest.mark.gpu
-def test_figfill_mp_two_ranks_on_the_device(tmp_path):
+@pytest.mark.parametrize("name", ["threads3", "ot_carry_t3"])
+def test_figfill_mp_two_ranks_on_the_device(name, tmp_path):
     """The launcher's N = 2 path with the real library: two rank processes share the box's one MI355X (gloo for the
-    all-gather, since RCCL refuses two ranks on one device), each fills its shard through libfighip.so, rank 0 writes.  On the
-    `threads3` fixture, so the per-process overlap_threshold presets travel with the shards."""
+    exchanges, since RCCL refuses two ranks on one device), each fills its shard through libfighip.so, rank 0 writes.  On the
+    `threads3` / `ot_carry_t3` fixtures, whose per-process overlap_threshold carry crosses the shards (the reach bits measured
+    by fig_probe_kernel on one rank decide the preset of a gap on the other)."""
     import torch.multiprocessing as mp
-    root = util.extract_golden("threads3", str(tmp_path))
+    root = util.extract_golden(name, str(tmp_path))
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    ps = [ctx.Process(target=_mp_worker, args=(r, 2, port, root, "threads3", q, None)) for r in range(2)]
+    ps = [ctx.Process(target=_mp_worker, args=(r, 2, port, root, name, q, None)) for r in range(2)]
     for p in ps:
         p.start()
     outs = [q.get(timeout=600) for _ in ps]
@@ -344,7 +346,7 @@ def _figfill_devices(root, exe, devices, serial=False):
     return util.run([exe] + util.meta(root)["fillgaps_argv"], root, env)
 
 
-@pytest.mark.parametrize("name,devices", [("threads3", "0,0"), ("unmapped_mid_err", "0,0,0"), ("partial_brackets", "0,0")])
+@pytest.mark.parametrize("name,devices", [("threads3", "0,0"), ("unmapped_mid_err", "0,0,0"), ("partial_brackets", "0,0"), ("ot_carry", "0,0"), ("ot_carry_t3", "0,0,0")])
 def test_figfill_devices_from_the_cpp_host_emulation(name, devices, tmp_path):
     """N GPUs from the C++ host (FIGFILL_DEVICES, figfill_main.cpp: fill_multi): LPT shards in C++, one fig_ctx and host thread
     per listed device, results merged in host memory -- here on the one-lane emulation library (every "device" is ordinal 0),
@@ -389,11 +391,12 @@ def test_cpp_partition_matches_the_python_partition(tmp_path):
 def test_figfill_devices_two_contexts_on_the_device(tmp_path):
     """FIGFILL_DEVICES on the MI355X box: two fig_ctx of the real library fill their shards concurrently from two host threads
     (both on the box's one GPU), merged by the C++ host: the reference's files, byte for byte."""
-    root = util.extract_golden("threads3", str(tmp_path))
-    r = _figfill_devices(root, util.FIGFILL, "0,0")
-    assert r.returncode == 0, r.stderr
-    for fn in util.ref_files(root):
-        assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), fn
+    for k, name in enumerate(("threads3", "ot_carry", "ot_carry_t3")):        # ot_carry*: the reach bits of one shard decide the other's carry
+        root = util.extract_golden(name, str(tmp_path / f"g{k}"))
+        r = _figfill_devices(root, util.FIGFILL, "0,0")
+        assert r.returncode == 0, r.stderr
+        for fn in util.ref_files(root):
+            assert util.read(os.path.join(root, "tmp", fn)) == util.read(os.path.join(root, "ref", fn)), (name, fn)
     root2 = util.extract_golden("bench_b25", str(tmp_path / "b"))
     r = _figfill_devices(root2, util.FIGFILL, "0,0")
     assert r.returncode == 0, r.stderr

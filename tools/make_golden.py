@@ -42,8 +42,22 @@ CASES = {
     # feed the insert-size histogram (:907-914).  The case carries a second, 400-bp scaffold with 260 model pairs of ~300 bp
     # inserts: counted with the flag off (inputMean = 0), dropped with it on, which moves the model's mean / SD / thresholds.
     "inputmean": dict(seed=103, mode="unmapped", gap_specs=[(3000, 30), (6000, 90)], coverage=12, err=0.005, n_model_pairs=700),
+    # ---- round 4: the carry of the process-global overlap_threshold (Figbird.cpp:103, :6298-6317; read at :2684, :2760-2766).
+    # The FIRST gap of a worker process closes by a negative overlap at its first candidate (gap 0: 10 N, flanks overlapping by
+    # 14 bp), so that process's loop leaves at :6306 without getting to :6317; the process's NEXT gap sits 8 bp from the contig
+    # end (side_limit < 10, :6303: leaves before :6317 too) and reaches finalize's detect_overlap_gapestimate (:5517) with the
+    # global still 0 -- where a carry predicted from contig geometry alone hands it 5.  Its hand-placed partial reads overhang
+    # from both sides and overlap by 3 bases (overlap counts of 1..4 are what 0 vs 5 decides, :2684).  `ot_carry`: one worker
+    # process {0, 1}; `ot_carry_t3`: $num_threads = 3 deals the four gaps {0, 3}, {1}, {2} (FillGaps.cpp:538-579).
+    # (The gap is 52 bp long because such a gap also reads the never-written used_read_arr[0], Figbird.cpp:6265 / :6547: at 52
+    # bp the stack residue is 0 in the -O0 build FillGaps compiles and in oracle/_ref's -O2 build alike, which is the value the
+    # oracle and the engine take; at most other lengths the reference's two builds disagree with each other.)
+    "ot_carry": dict(seed=4, mode="partial", gap_specs=[(2500, 10), (5940, 52)], contig_len=6000, insert_mean=180, insert_sd=10, coverage=30, err=0.003,
+                     n_model_pairs=600, neg_overlap_gaps={0: (10, 14)}),
+    "ot_carry_t3": dict(seed=5, mode="partial", gap_specs=[(1500, 10), (3000, 30), (4400, 45), (5940, 52)], contig_len=6000, insert_mean=180, insert_sd=10,
+                        coverage=30, err=0.003, n_model_pairs=600, neg_overlap_gaps={0: (10, 14)}),
 }
-N_THREADS = {"threads3": 3}
+N_THREADS = {"threads3": 3, "ot_carry_t3": 3}
 SET_INPUTMEAN = {"inputmean": 1}
 
 
@@ -107,6 +121,23 @@ def _post_threads3(case):
         g.partial = reads
 
 
+def _post_ot_carry(case):
+    """The last gap (8 bp before the contig end): right-anchored reads (8 aligned bases, all the flank there is) covering its last
+    L - 8 bases and left-anchored reads hanging far enough into the gap to overlap them by 3 and by 0 bases."""
+    s = case.scaffolds[0]; L = case.read_len
+    g = case.gaps[-1]
+    assert len(s) - (g.start + g.length) == 8
+    reads = []
+    c_right = L - 8
+    for k in (g.length - c_right + 3, g.length - c_right, g.length - c_right + 3):
+        al = L - k; pos1 = g.start - al + 1
+        reads.append(synth.PartialRead(s[g.start - al:g.start] + g.truth[:k], g.start - pos1, 1, pos1, f"{al}M{k}S", -1, "I" * L))
+    for c in (c_right, c_right):
+        al = L - c
+        reads.append(synth.PartialRead(g.truth[len(g.truth) - c:] + s[g.start + g.length:g.start + g.length + al], c, 2, g.start + g.length + 1, f"{c}S{al}M", -1, "I" * L))
+    g.partial = reads
+
+
 def _post_inputmean(case):
     rng = synth.np.random.default_rng(synth.np.random.PCG64(1031))
     short = synth._rand_seq(rng, 400)
@@ -122,7 +153,7 @@ def _post_inputmean(case):
     case.n_pairs = len(case.myout) // 2
 
 
-POST = {"inputmean": _post_inputmean, "threads3": _post_threads3, "edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
+POST = {"ot_carry": _post_ot_carry, "ot_carry_t3": _post_ot_carry, "inputmean": _post_inputmean, "threads3": _post_threads3, "edge_no_reads": _post_edge_no_reads, "repeat_flanks": _post_repeat_flanks, "cap_3001": _post_cap_3001, "stat2_hint": _post_stat2_hint}
 
 
 def make(name):
