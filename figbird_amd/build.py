@@ -54,6 +54,15 @@ def build_lib(force: bool = False) -> str:
     return LIB
 
 
+def build_prof_lib() -> str:
+    """Diagnostic build with the per-wave phase timers (-DFIG_PROF, fig_engine.h): libfighip_prof.so, never shipped or loaded by
+    default (tools/gpu_probe.py takes it through FIG_LIB)."""
+    out = os.path.join(LIBDIR, "libfighip_prof.so")
+    if not _newer(out, _csrc_files()):
+        _run([HIPCC] + HIP_FLAGS + ["-DFIG_PROF", "-o", out, os.path.join(CSRC, "fig_abi.hip")])
+    return out
+
+
 def _host_sources():
     host = os.path.join(CSRC, "host")
     hdrs = sorted(os.path.join(host, f) for f in os.listdir(host) if f.endswith(".h"))

@@ -160,9 +160,94 @@ FIG_D void fig_find_repeat(FigEng &E) {
     FIG_SYNC();
 }
 
+// update_partial_prob with lanes = gap columns (no atomics on the counts, no per-base global loads): the reads' packed words
+// and their column maps are staged once in the idle weight-row area of LDS (read p covers columns [ja, jb) with base index
+// i = j + off: off = clip + 1 from the left flank, clip - gaplen from the right), then every column walks the reads.  The counts
+// are integers, so the order is immaterial (as in the form below, which stays for gaps whose reads do not fit the area).
+FIG_D bool fig_update_partial_prob_cols(FigEng &E, int gaplen) {
+    FigState &S = *E.S;
+    const int cg = E.capG, np = E.g->nP;
+    const int RW = 28;                                             // dwords per staged read: 4 of column map + up to 13 + 7 packed words (+ pad)
+    if (!E.w_lds || np < 1 || (long long)np * RW * 4 > (long long)E.nteams * E.Wcap * 8) return false;
+    uint32_t *st = (uint32_t *)(fig_lds + E.off_w);
+    const FigDevReads &PR = E.B->p;
+    const long long pb = E.g->pBase;
+    if (E.tid == 0) { S.left_max = -FIG_MAX_GAP; S.right_min = FIG_MAX_GAP; }
+    FIG_SYNC();
+    for (int p = E.tid; p < np; p += E.nt) {
+        const long long idx = pb + p;
+        const int len = PR.len[idx], match = PR.aux[idx];
+        int clip = PR.clip[idx];
+        fig_atomic_max_i32(&S.partial_read_len, len);
+        const int rf = E.scr.repeatflag[p * 3];
+        if (rf == 1) clip = E.scr.repeatflag[p * 3 + 2] + E.scr.repeatflag[p * 3 + 1] - 1;
+        if (rf == 2) clip = E.scr.repeatflag[p * 3 + 1];
+        int stop1 = len - clip - 1; if (stop1 > gaplen) stop1 = gaplen;
+        const int stop2 = (clip <= gaplen) ? 0 : clip - gaplen;
+        int ja = 0, jb = 0, off = 0;
+        if (match == 1 || match == 4) {
+            const int n = stop1 > 0 ? stop1 : 0;
+            ja = 0; jb = n; off = clip + 1;
+            fig_atomic_max_i32(&S.left_max, n - 1);
+        } else if (match == 2 || match == 3) {
+            const int n = clip - 1 >= stop2 ? clip - stop2 : 0;   // bases clip-1 .. stop2 -> columns gaplen-1 .. gaplen-n
+            ja = gaplen - n; jb = gaplen; off = clip - gaplen;
+            fig_atomic_min_i32(&S.right_min, gaplen - n);
+        }
+        uint32_t *r = st + (long long)p * RW;
+        r[0] = (uint32_t)ja; r[1] = (uint32_t)jb; r[2] = (uint32_t)off; r[3] = (uint32_t)len;
+    }
+    for (int i = E.tid; i < np * 24; i += E.nt) {                  // packed 2-bit words then N-mask words of every read
+        const int p = i / 24, k = i - p * 24;
+        const int len = PR.len[pb + p];
+        const int nw2 = (len + 15) >> 4, nwm = (len + 31) >> 5;
+        st[(long long)p * RW + 4 + k] = k < nw2 + nwm ? E.B->packed[PR.woff[pb + p] + k] : 0u;
+    }
+    FIG_SYNC();
+    for (int j = E.tid; j < gaplen; j += E.nt) {
+        int c0 = 1, c1 = 1, c2 = 1, c3 = 1;
+        if (j < cg) {
+            for (int p = 0; p < np; p++) {
+                const uint32_t *r = st + (long long)p * RW;
+                const int ja = (int)r[0], jb = (int)r[1];
+                if (j < ja || j >= jb) continue;
+                const int i = j + (int)r[2], len = (int)r[3];
+                int c = 4;
+                if (i >= 0 && i < len) {
+                    const int nw2 = (len + 15) >> 4;
+                    const uint32_t w = r[4 + (i >> 4)], m = r[4 + nw2 + (i >> 5)];
+                    c = ((m >> (i & 31)) & 1) ? 4 : (int)((w >> ((i & 15) * 2)) & 3);
+                }
+                c0 += (c == 0 || c == 4); c1 += (c == 1 || c == 4); c2 += (c == 2 || c == 4); c3 += (c == 3 || c == 4);
+            }
+        }
+        E.scr.pc[j] = c0; E.scr.pc[cg + j] = c1; E.scr.pc[2 * cg + j] = c2; E.scr.pc[3 * cg + j] = c3;
+        const int total = c0 + c1 + c2 + c3;
+        int max_index = 0, max_val = c0;
+        if (c1 > max_val) { max_val = c1; max_index = 1; }
+        if (c2 > max_val) { max_val = c2; max_index = 2; }
+        if (c3 > max_val) { max_val = c3; max_index = 3; }
+        E.scr.colchar[j] = (unsigned char)max_index;
+        FIG_PQ(E, 0, j).p = (double)c0 / total; FIG_PQ(E, 1, j).p = (double)c1 / total; FIG_PQ(E, 2, j).p = (double)c2 / total; FIG_PQ(E, 3, j).p = (double)c3 / total;
+    }
+    FIG_SYNC();
+    if (E.tid == 0 && E.M->partial_flag == 1) S.partial_read_count = np;
+    if (E.tid == 0) {
+        int lc = 0, rc = 0;
+        for (int i = 0; i < gaplen; i++) {
+            if (i <= S.left_max - 5) { if (lc < 99) S.partial_left[lc++] = E.scr.colchar[i]; }
+            else if (i >= S.right_min + 5) { if (rc < 99) S.partial_right[rc++] = E.scr.colchar[i]; }
+        }
+        S.pl_len = lc; S.pr_len = rc;
+    }
+    FIG_SYNC();
+    return true;
+}
+
 // update_partial_prob, Figbird.cpp:1913-2088.  Lanes = partial reads (integer counts, so the
 // order of the increments is immaterial), then lanes = columns.
 FIG_D void fig_update_partial_prob(FigEng &E, int gaplen) {
+    if (fig_update_partial_prob_cols(E, gaplen)) return;
     FigState &S = *E.S;
     int cg = E.capG, np = E.g->nP;
     for (int i = E.tid; i < gaplen; i += E.nt) { E.scr.pc[i] = 1; E.scr.pc[cg + i] = 1; E.scr.pc[2 * cg + i] = 1; E.scr.pc[3 * cg + i] = 1; }
@@ -599,6 +684,7 @@ FIG_D void fig_seed_reweight(FigEng &E) {
 }
 
 #include "fig_engine_hot.h"
+#include "fig_engine_partial.h"
 
 // Numeric planes (i)/(ii) of the parity contract for the candidate being evaluated (parity tests only; all lanes).
 FIG_D void fig_dbg_planes(FigEng &E, int nreads) {
@@ -659,7 +745,11 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         if ((long long)nrow * rstride > (long long)E.nteams * E.Wcap) { nrow = E.nw < E.nteams ? E.nw : E.nteams; if (nrow > FIG_PLB_TEAMS) nrow = FIG_PLB_TEAMS; rstride = E.Wcap; }
         if (nrow < 1) nrow = 1;
         FIG_TICK(E, 31);
-        for (int p0 = 0; p0 < nproc; p0 += nrow) {
+        // the form of fig_engine_partial.h where it applies (LDS table, no N base in the gap's partial reads, no clipping by the
+        // contig start); otherwise the generic form below
+        const bool pfast = fig_partial_fast<LDS>(E);
+        if constexpr (LDS) { if (pfast) fig_partial_estep<LDS>(E, gapoffset, nproc, maxLikelihood, pfl); }
+        for (int p0 = 0; p0 < nproc && !pfast; p0 += nrow) {
             const int nr = nproc - p0 < nrow ? nproc - p0 : nrow;
             if (E.wave < nr) {
                 const int p = p0 + E.wave;
@@ -731,7 +821,8 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         FIG_TICK(E, 32);
         const double *Ctab = (const double *)E.pq;
         // one read per wave, no workgroup barrier inside the loop (the per-read results are independent)
-        for (int p = E.wave; p < nproc; p += E.nw) {
+        if constexpr (LDS) { if (pfast) fig_partial_mle<LDS>(E, gapoffset, nproc, pfl, pml); }
+        for (int p = E.wave; p < nproc && !pfast; p += E.nw) {
             unsigned char *rbw = (unsigned char *)E.plb + (E.wave % FIG_PLB_TEAMS) * 256;
             const int len = PR.len[pb + p], flag1 = PR.aux[pb + p];
             { const long long woff = PR.woff[pb + p]; for (int j = E.lane; j < len; j += E.wsz) rbw[j] = (unsigned char)fig_read_code(E.B->packed, woff, len, j); }
@@ -787,9 +878,9 @@ FIG_D void fig_place_reads(FigEng &E, int ge, int finalize_flag, int gapoffset, 
         { unsigned long long t = pml; for (int off = 32; off > 0; off >>= 1) t += fig_shfl_down_u64(t, off); E.mle_exec += t; }   // unpruned: executed == credited
         FIG_SYNC();
         FIG_TICK(E, 5);
+        int ret_val[2] = {0, 0};
+        fig_detect_overlap_par<LDS>(E, E.scr.pflag, 2, G, ret_val, 8);      // all threads; result in thread 0
         if (E.tid == 0) {
-            int ret_val[2] = {0, 0};
-            fig_detect_overlap(E, E.scr.pflag, 2, G, ret_val, 8);
             if (ret_val[0] == 300) maxLikelihood += ret_val[0];
             else if (ret_val[0] >= 1 && ret_val[0] < FIG_MAX_READLEN) maxLikelihood += 30 * ret_val[0];
             else if (ret_val[1] == -1) maxLikelihood += -100;

@@ -128,8 +128,10 @@ FIG_D void fig_eval_candidate(FigEng &E) {
     const int G0 = E.g->G0;
     const int gapEstimate = S.L.gapEstimate, j = S.L.j, inr = S.L.inr, finalize_flag = S.L.finalize_flag;
     FIG_SYNC();
+    FIG_T0(E);
     if (E.tid == 0) { S.umaxleftf = S.umaxrightf = S.ucoverf = 0; S.L.ev_side_break = 0; S.L.ev_iters = 0; S.dbg_j = j; }
     int fill = fig_initialize(E, gapEstimate, j);
+    FIG_TICK(E, 35);
     if (S.side_limit < 10) { if (E.tid == 0) { S.L.ev_side_break = 1; S.L.ev_fill = fill; S.dbg_j = -1; } FIG_SYNC(); return; }
     if (S.one_side_repeat_flag == 1) fill = 0;
     if (E.tid == 0) S.L.ev_fill = fill;
@@ -142,8 +144,10 @@ FIG_D void fig_eval_candidate(FigEng &E) {
         if (E.tid == 0) { S.valid_count = 0; S.invalid_count = 0; }
         FIG_SYNC();
         fig_place_reads<LDS>(E, i, finalize_flag, gapEstimate - G0, S.large_gap_flag);
+        FIG_TICK(E, 38);
         fig_compute_probs(E);
         FIG_SYNC();
+        FIG_TICK(E, 36);
         if (M.unmapped) {
             if (S.comp_count >= 5) break;
             if (S.large_gap_flag == 1 && S.region_perct * gapEstimate < preset_unfilled_len) break;
@@ -157,6 +161,7 @@ FIG_D void fig_eval_candidate(FigEng &E) {
     fig_compute_sequence(E, 0, 0);
     if (E.tid == 0) { S.L.likelihood = S.lik; S.L.ev_iters = i; S.dbg_j = -1; }
     FIG_SYNC();
+    FIG_TICK(E, 37);
 }
 
 // ---- bookkeeping after a candidate (:6358-6480): best tracking, early-stop heuristics.  Consumes the outputs
@@ -381,8 +386,10 @@ FIG_D void fig_bind(FigEng &E, const FigScr &work, const FigPersist &P, int mode
 // One speculative candidate: load the gap's snapshot, evaluate candidate j, write the slot.
 template <bool LDS>
 FIG_D void fig_spec_eval(FigEng &E, const FigScr &work, const FigPersist &P, int j, int slot, int capGg) {
+    FIG_T0(E);
     fig_bind(E, work, P, FIG_BIND_EVAL, slot, capGg);
     fig_state_load(E, P);
+    FIG_TICK(E, 34);
     FigState &S = *E.S;
     const unsigned long long flops0 = E.flops;
     if (E.tid == 0) {
@@ -395,6 +402,7 @@ FIG_D void fig_spec_eval(FigEng &E, const FigScr &work, const FigPersist &P, int
     if (j == 0) for (int x = E.tid; x < S.prev_len; x += E.nt) E.scr.prev[x] = P.prev[x];
     FIG_SYNC();
     fig_eval_candidate<LDS>(E);
+    FIG_TICK(E, 26);                                 // (everything inside fig_eval_candidate, which has its own slots)
     if (E.tid == 0) {
         FigSlot *h = fig_slot_hdr(P, slot);
         h->lik = S.L.likelihood; h->region_perct = S.region_perct; h->end_pos_max = S.end_pos_max;
@@ -409,9 +417,17 @@ FIG_D void fig_spec_eval(FigEng &E, const FigScr &work, const FigPersist &P, int
         unsigned char *pv = fig_slot_prev(P, slot, capGg);
         for (int x = E.tid; x < S.prev_len; x += E.nt) pv[x] = E.scr.prev[x];
     }
-    if (E.flops != flops0) { fig_atomic_add_u64(&fig_slot_hdr(P, slot)->flops, E.flops - flops0); fig_atomic_add_u64(&E.B->counters[2], E.flops - flops0); }
+    {   // one atomic pair per wave, not per lane (a partial-mode candidate is ~1 ms of work: 512 same-address atomics showed up in its profile)
+        unsigned long long d = E.flops - flops0;
+#ifndef FIG_EMU
+        for (int off = 32; off > 0; off >>= 1) d += fig_shfl_down_u64(d, off);
+        if (E.lane != 0) d = 0;
+#endif
+        if (d) { fig_atomic_add_u64(&fig_slot_hdr(P, slot)->flops, d); fig_atomic_add_u64(&E.B->counters[2], d); }
+    }
     E.flops = flops0;                             // speculative work is credited by the replay, and only if it is consumed
     FIG_SYNC();
+    FIG_TICK(E, 39);
 }
 
 // Replay the bookkeeping of up to n speculated candidates (slots 0..n-1 hold candidates j0, j0+1, ...).

@@ -157,6 +157,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
             for (int64_t r = r0; r < r0 + n; r++) {
                 int len = (int)(b->p_seq_off[r + 1] - b->p_seq_off[r]);
                 if (len > FIG_MAX_READLEN || len > m->max_read_length || len < 1) return FIG_EUNSUP;   // the {1-e,e} pair tables hold max_read_length entries
+                { const char *rs_ = b->p_seq + b->p_seq_off[r]; for (int q = 0; q < len; q++) if (code_of(rs_[q]) > 3) { d.pad |= 1; break; } }   // bit 0: the gap has a partial read with a base outside ACGT (fig_engine_partial.h)
                 K.p_pos.push_back(b->p_pos[r]); K.p_aux.push_back(b->p_match[r]); K.p_clip.push_back(b->p_clipped_index[r]);
                 K.p_ref.push_back(b->p_ref_pos[r]); K.p_len.push_back(len);
                 K.p_woff.push_back((int64_t)K.packed.size());
@@ -192,7 +193,7 @@ static int fig_pack(const fig_model *m, const fig_gap_batch *b, size_t state_byt
         // process taking the gaps in batch order (numthreads = 1)
         K.ot_given = b->gap_ot_preset != nullptr;
         K.ot_preset.assign((size_t)std::max<int64_t>(ng, 1), 0);
-        for (int64_t g = 0; g < ng; g++) { K.gaps[g].pad = 0; if (b->gap_ot_preset) K.ot_preset[(size_t)g] = b->gap_ot_preset[g] ? 1 : 0; }
+        for (int64_t g = 0; g < ng; g++) if (b->gap_ot_preset) K.ot_preset[(size_t)g] = b->gap_ot_preset[g] ? 1 : 0;
     }
     // ---- launch classes by the longest candidate a gap can reach (LDS columns); within a class the most
     // expensive gaps come first.  gmax: candidate range (:6237-6238), checkGapReads probes (:6121-6153).

@@ -47,7 +47,7 @@ struct FigDevGap {
     int64_t strOff;                  // offset of this gap's result string
     int32_t gapNo; int32_t cls;
     int64_t persistOff;              // this gap's persistent slab (candidate-parallel mode)
-    int32_t capGg, rangeCap, nslots, pad;   // (pad: unused)
+    int32_t capGg, rangeCap, nslots, pad;   // pad bit 0: a partial read of the gap holds a base outside ACGT
     int64_t streamOff;               // first dword of this gap's operand-select stream (FigDevBatch::ustream)
 };
 

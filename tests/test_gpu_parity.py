@@ -325,3 +325,36 @@ def test_loguniform_mix_sample_matches_oracle(tmp_path):
             sample.append(min(ids, key=lambda g: (nr[g] * (G[g] if G[g] <= 400 else 1), g)))
     assert len(sample) >= 7
     _oracle_compare(batch, res, sample, mc, spec, tmp_path, timeout=2400)
+
+
+def test_config5_mix_at_its_own_depth(tmp_path):
+    """BASELINE config 5 at its own depth: gap lengths log-uniform in [50, 2000], 256 gaps, ~1000 reads per gap (10^9 reads /
+    10^6 gaps).  The whole batch: two fills are identical (determinism) and the called bases equal the synthetic truth at the
+    substitution-error rate; one gap per length octave above 400 bp (one candidate length: seconds for the CPU) is compared
+    with the oracle byte for byte.  The <= 400-bp regime at this depth costs the oracle 10^2-10^3 s per gap and is pinned by
+    the committed bench_* goldens (same read length, insert size and depth)."""
+    spec = synth.BenchSpec(mode="unmapped", reads_per_gap_mean=1000.0, gap_mix="loguniform")
+    eng, mc = _bench_engine(spec)
+    batch, truth = synth.make_bench_batch(5005, 256, spec)
+    nr = np.diff(batch.u_read_off); G = np.asarray(batch.gap_len)
+    assert 800 < float(nr.mean()) < 1200 and int(G.min()) >= 50 and int(G.max()) <= 2000
+    eng.upload(batch)
+    r1 = eng.fill_resident()
+    r2 = eng.fill_resident()
+    eng.free_batch(); eng.close()
+    assert _loaded_native()
+    assert r1.strings == r2.strings and list(r1.filled_len) == list(r2.filled_len) and list(r1.gaptofill) == list(r2.gaptofill)
+    called = wrong = 0
+    for s, t in zip(r1.strings, truth):
+        t = t.tobytes().decode()
+        if len(s) == len(t):
+            called += sum(1 for a in s if a != "N")
+            wrong += sum(1 for a, b in zip(s, t) if a != "N" and a != b)
+    assert called > 20000 and wrong <= 0.002 * called, (called, wrong)
+    sample = []
+    for lo, hi in [(401, 800), (800, 1217), (1217, 1601), (1601, 2001)]:
+        ids = [g for g in range(batch.n_gaps) if lo <= G[g] < hi and nr[g] <= 3000]
+        if ids:
+            sample.append(min(ids, key=lambda g: (nr[g], g)))
+    assert len(sample) == 4
+    _oracle_compare(batch, r1, sample, mc, spec, tmp_path, timeout=2400)

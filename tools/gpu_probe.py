@@ -25,6 +25,8 @@ if __name__ == "__main__":
     rpg = float(sys.argv[4]) if len(sys.argv) > 4 else 1000.0
     spec = synth.BenchSpec(mode=mode) if mode == "unmapped" else synth.BenchSpec(mode="partial", read_len=101, insert_mean=180, insert_sd=10)
     spec.reads_per_gap_mean = rpg
+    if mode == "partial" and len(sys.argv) > 4:
+        spec.partial_cov = int(rpg)                  # partial mode: argv[4] = soft-clipped reads drawn per gap (bench.py's partial pass: 48)
     m, mc = model_for(spec)
     print("model", m.Tmin, m.Tmax, m.cutoff, m.stats, flush=True)
     eng = api.Engine(0, lib_path=os.environ.get("FIG_LIB"))
