@@ -419,6 +419,7 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
             }
         }
     }
+    FIG_SYNC();                                        // the caller re-initialises pflag for the MLE pass: not before the first wave has read it
     maxLikelihood_out = maxLikelihood; pfl_out += pfl;
 }
 

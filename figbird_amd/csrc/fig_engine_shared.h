@@ -114,8 +114,12 @@ typedef FigState __attribute__((address_space(3))) *fig_lsp;
 // ---- the indexed multiplies.  F0..F7 and the constant 1.0 are pinned to v[232:249]; p* are the products (any registers);
 // w* hold two 16-bit entries of the operand-select stream each: the value M0 takes (0x1000 = "SRC0 is indexed" | register
 // offset 2 * (4 * reverse + base), or 16 = the 1.0 for a slot without a regular read).  Per multiply ONE SALU instruction.
-// The blocks write M0 (and leave index mode off again): M0 is in their clobber lists so that the compiler neither keeps a value
-// of its own in M0 across them nor hoists an M0 initialisation past them.
+// The blocks write M0 (and leave index mode off again).  M0 cannot be named in the clobber list: the AMDGPU backend treats it as a
+// reserved register ("inline asm clobber list contains reserved registers: m0 ... may not be preserved"), i.e. the list entry
+// is ignored and only buys a warning per instantiation.  What makes the blocks safe is that nothing else in these kernels
+// lives in M0 across them: gfx950 needs M0 for s_sendmsg, LDS-DMA, s_movrel and the GWS/ordered-count DS operations only,
+// none of which the engine uses -- tools/isa_m0_check.py verifies on the compiled ISA that every M0 access of a function that
+// enters index mode belongs to one of these blocks.
 #define FIG_SH_M2(pa, pb, w) \
     "s_and_b32 m0, " w ", 0xffff\n v_mul_f64 " pa ", v[232:233], " pa "\n" \
     "s_lshr_b32 m0, " w ", 16\n v_mul_f64 " pb ", v[232:233], " pb "\n"
@@ -124,13 +128,13 @@ typedef FigState __attribute__((address_space(3))) *fig_lsp;
 FIG_FI void fig_sh_mul4(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]") "s_set_gpr_idx_off\n"
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3])
-                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]) : "scc", "m0");
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]) : "scc");
 }
 FIG_FI void fig_sh_mul8(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
                  FIG_SH_M2("%[p4]", "%[p5]", "%[w2]") FIG_SH_M2("%[p6]", "%[p7]", "%[w3]") "s_set_gpr_idx_off\n"
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7])
-                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]) : "scc", "m0");
+                 : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]) : "scc");
 }
 FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t *w) {
     asm volatile("s_set_gpr_idx_on %[w0], 1\n" FIG_SH_M2("%[p0]", "%[p1]", "%[w0]") FIG_SH_M2("%[p2]", "%[p3]", "%[w1]")
@@ -139,7 +143,7 @@ FIG_FI void fig_sh_mul16(double *p, const double *f, double one, const uint32_t 
                  : [p0] "+v"(p[0]), [p1] "+v"(p[1]), [p2] "+v"(p[2]), [p3] "+v"(p[3]), [p4] "+v"(p[4]), [p5] "+v"(p[5]), [p6] "+v"(p[6]), [p7] "+v"(p[7]),
                    [p8] "+v"(p[8]), [p9] "+v"(p[9]), [p10] "+v"(p[10]), [p11] "+v"(p[11]), [p12] "+v"(p[12]), [p13] "+v"(p[13]), [p14] "+v"(p[14]), [p15] "+v"(p[15])
                  : FIG_SH_FIN, [w0] "s"(w[0]), [w1] "s"(w[1]), [w2] "s"(w[2]), [w3] "s"(w[3]), [w4] "s"(w[4]), [w5] "s"(w[5]), [w6] "s"(w[6]), [w7] "s"(w[7])
-                 : "scc", "m0");
+                 : "scc");
 }
 
 // ---- the chain: NS products per lane over the L steps of the chunk.  colp = PQ + x (x = o + xoff: the lane's first column),

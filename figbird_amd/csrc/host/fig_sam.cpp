@@ -14,6 +14,13 @@
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
+#include <chrono>
+#include <string_view>
+#include <thread>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 namespace figsam {
 namespace {
@@ -35,7 +42,13 @@ struct State {
     // per-gap bookkeeping
     std::vector<int> read_count, partial_read_count;
     std::vector<std::vector<std::string>> jump_reads;       // unmapped_jump_reads
-    std::vector<std::unordered_set<std::string>> jump_set, partial_set;
+    std::vector<std::unordered_set<std::string>> partial_set;
+    // index of the duplicate test's substring scan (dup_jump): per gap, every window of length jump_wlen[g] of every kept read,
+    // keyed by its hash -> (read, offset); jump_wlen[g] = (length of the gap's first kept read) - 4, i.e. the core length of a
+    // query of that same length
+    struct Win { size_t h; uint32_t read, off; };
+    std::vector<std::vector<Win>> jump_win;              // (a gap keeps a few dozen reads: a flat list scanned for the hash beats a node-based map)
+    std::vector<long> jump_wlen;
     std::vector<std::string> gap_text, partial_text;
     std::vector<int> perfect_gap, perfect_len;
     // interval index: per contig the gap ids in file order, plus whether starts/ends ascend (then binary search applies)
@@ -76,12 +89,10 @@ void account_myout_line(State &S, const char *p, size_t n) {
 void myout_line(State &S, const Sam &r);
 
 std::string revcomp(const std::string &s) {     // reverse(), :145-166
+    static const struct Tab { char c[256]; Tab() { memset(c, 'N', sizeof c); c[(unsigned char)'A'] = 'T'; c[(unsigned char)'C'] = 'G'; c[(unsigned char)'G'] = 'C'; c[(unsigned char)'T'] = 'A'; } } tab;
     std::string r(s.size(), 'N');
-    for (size_t i = 0; i < s.size(); i++) {
-        char ch = s[i], o = 'N';
-        if (ch == 'A') o = 'T'; else if (ch == 'C') o = 'G'; else if (ch == 'G') o = 'C'; else if (ch == 'T') o = 'A';
-        r[s.size() - 1 - i] = o;
-    }
+    const size_t n = s.size();
+    for (size_t i = 0; i < n; i++) r[n - 1 - i] = tab.c[(unsigned char)s[i]];
     return r;
 }
 
@@ -158,18 +169,28 @@ void parse_cigar(State &S, const std::string &cigar, int readlen) {      // pars
 }
 
 bool check_char(const std::string &r) {             // checkChar, :868-883: true = has a character outside ACGTNacgtn
-    for (char c : r) if (!strchr("ACGTNacgtn", c)) return true;
+    static const struct Tab { bool ok[256]; Tab() { memset(ok, 0, sizeof ok); for (const char *p = "ACGTNacgtn"; *p; p++) ok[(unsigned char)*p] = true; } } tab;
+    for (char c : r) if (!tab.ok[(unsigned char)c]) return true;       // (a NUL inside the string counts as outside, as strchr(..., 0) != NULL never arises for std::string data)
     return false;
 }
 bool ncount_ok(const std::string &r) { int c = 0; for (char ch : r) if (ch == 'N') c++; return c <= 3; }      // check_Ncount_partial, :857-866
 
 bool dup_jump(State &S, const std::string &read, int g) {      // check_duplicate, samflag 2 (:369-387)
-    if (S.jump_set[g].count(read)) return true;
+    // (the reference first looks for an identical kept read, :369-375: an identical read also holds the clipped core as a
+    //  substring, and with an empty core any kept read makes the test true, so the scan below decides both)
     if (S.read_count[g] == 0) return false;
     const std::string core = read.size() >= 4 ? read.substr(2, read.size() - 4) : std::string();       // clip 2 from either end
     // (memmem: glibc's vectorised two-way search; this scan over every read already kept for the gap is the reference's own
     //  quadratic duplicate test and dominates the ingest at thousands of reads per gap)
     if (core.empty()) return !S.jump_reads[g].empty();
+    if ((long)core.size() == S.jump_wlen[g]) {
+        // every kept read that is long enough has all its windows of this length in the index: a hash hit verified by memcmp
+        // is "core is a substring of a kept read", and no hit means none is
+        const size_t h = std::hash<std::string_view>()(std::string_view(core));
+        for (const State::Win &w : S.jump_win[g])
+            if (w.h == h && memcmp(S.jump_reads[g][w.read].data() + w.off, core.data(), core.size()) == 0) return true;
+        return false;
+    }
     for (const std::string &s1 : S.jump_reads[g]) if (s1.size() >= core.size() && memmem(s1.data(), s1.size(), core.data(), core.size())) return true;
     return false;
 }
@@ -340,7 +361,14 @@ void print_vectors(State &S, std::vector<Sam> &reads1, std::vector<Sam> &reads2)
     reads1.clear(); reads2.clear();
 }
 
-void store_jump(State &S, int g, const std::string &seq) { S.jump_reads[g].push_back(seq); S.jump_set[g].insert(seq); S.read_count[g]++; }
+void store_jump(State &S, int g, const std::string &seq) {
+    if (S.jump_reads[g].empty()) S.jump_wlen[g] = seq.size() > 4 ? (long)seq.size() - 4 : -1;
+    const uint32_t idx = (uint32_t)S.jump_reads[g].size();
+    S.jump_reads[g].push_back(seq); S.read_count[g]++;
+    const long w = S.jump_wlen[g];
+    if (w > 0 && (long)seq.size() >= w)
+        for (uint32_t o = 0; o + (size_t)w <= seq.size(); o++) S.jump_win[g].push_back({std::hash<std::string_view>()(std::string_view(seq.data() + o, (size_t)w)), idx, o});
+}
 
 void print_mixed(State &S, std::vector<Sam> &m1, std::vector<Sam> &m2) {              // printMixedVectors, :999-1489
     const int maxD = S.a.maxDistance, samflag = S.a.samflag;
@@ -433,10 +461,451 @@ bool load_contigs(const std::string &path, std::vector<std::string> &contigs, st
     return true;
 }
 
+
+// =====================================================================================================================
+// The fast form of the stage (round 4).  Same decisions, same bytes; what changes is how the records travel:
+//   * the SAM is mapped once and parsed once, in parallel chunks, into 48-byte records of offsets into the mapping (the
+//     reference -- and the legacy form above -- tokenises every line into seven heap strings, twice for a far jump library);
+//   * the two passes of a far jump library (:2278-2435 insert-size mean, :2437-2566 binning) and the pair-grouping logic walk
+//     that array; records that go to myout.sam are only NOTED (record, IH) and the insert-size histogram is fed from the
+//     parsed fields (what processMapping would re-read from the line, :1768-1830);
+//   * myout.sam is formatted from the notes in parallel chunks and written with large writes.
+// The legacy form stays for inputs whose quirks the fast form does not restate: a line of 1023 bytes or more (the reference's
+// 1024-byte fgets splits it), a header line behind the first record, a record with fewer than 11 fields, the reduced-read
+// files (rewrite_readset reverses qualities in place and later writers see it), or FIGSAM_LEGACY=1 (A/B tests).
+// =====================================================================================================================
+typedef std::string_view sv;
+
+struct RecC {
+    uint64_t off;                                    // start of the line in the mapping
+    uint16_t qn_o, qn_l, rn_o, rn_l, cg_o, cg_l, sq_o, sq_l, ql_o, ql_l, md_o, md_l;
+    int32_t flag, pos, tlen, contigNo;
+};
+
+struct SamV {                                        // a record as the pair logic sees it: views into the mapping
+    sv qname, rname, cigar, seq, qual, md; int flag = 0, pos = 0, tlen = 0; long ih = 1, contigNo = -1;
+};
+
+inline int sv_atoi(const char *p, const char *e) {   // atoi on a token: optional sign, digits, stops at the first other character
+    long v = 0; bool neg = false;
+    if (p < e && (*p == '-' || *p == '+')) { neg = *p == '-'; p++; }
+    while (p < e && *p >= '0' && *p <= '9') { v = v * 10 + (*p - '0'); p++; }
+    return (int)(neg ? -v : v);
+}
+
+struct NameMap {                                     // getContigNo (:327-338): first contig of that name wins
+    std::vector<int> slot; std::vector<sv> key; std::vector<long> val; size_t mask = 0;
+    static uint64_t h(sv s) { uint64_t x = 1469598103934665603ull; for (char c : s) { x ^= (unsigned char)c; x *= 1099511628211ull; } return x; }
+    void build(const std::vector<std::string> &names, size_t n) {
+        size_t cap = 16; while (cap < 2 * n + 8) cap <<= 1;
+        mask = cap - 1; slot.assign(cap, -1);
+        for (size_t i = 0; i < n; i++) {
+            sv k(names[i]); size_t q = h(k) & mask; bool dup = false;
+            while (slot[q] >= 0) { if (key[(size_t)slot[q]] == k) { dup = true; break; } q = (q + 1) & mask; }
+            if (!dup) { slot[q] = (int)key.size(); key.push_back(k); val.push_back((long)i); }
+        }
+    }
+    long find(sv k) const {
+        if (slot.empty()) return -1;
+        size_t q = h(k) & mask;
+        while (slot[q] >= 0) { if (key[(size_t)slot[q]] == k) return val[(size_t)slot[q]]; q = (q + 1) & mask; }
+        return -1;
+    }
+};
+
+// one chunk of lines [b, e) of the mapping -> records; false when a line needs the legacy form
+bool parse_chunk(const char *base, size_t b, size_t e, const NameMap &names, std::vector<RecC> &out, bool &saw_record, bool &has_header, bool &header_after_record) {
+    sv last_name; long last_no = -1; bool have_last = false;
+    size_t p = b;
+    while (p < e) {
+        const char *ls = base + p;
+        const char *nl = (const char *)memchr(ls, '\n', e - p);
+        const size_t len = nl ? (size_t)(nl - ls) : e - p;
+        if (len + (nl ? 1 : 0) >= (size_t)kRec - 1) return false;          // fgets(line, 1024) would split it
+        p += len + (nl ? 1 : 0);
+        if (len == 0) return false;                                          // an empty line: get_sam fails on it (legacy decides)
+        if (ls[0] == '@') { has_header = true; if (saw_record) header_after_record = true; continue; }
+        saw_record = true;
+        RecC r; memset(&r, 0, sizeof r); r.off = (uint64_t)(ls - base);
+        const char *q = ls, *le = ls + len;
+        const char *tok[11]; const char *tend[11]; int nt = 0;
+        const char *mdp = nullptr, *mde = nullptr;
+        while (q < le) {
+            while (q < le && (*q == '\t' || *q == ' ')) q++;
+            if (q >= le) break;
+            const char *t0 = q;
+            while (q < le && *q != '\t' && *q != ' ') q++;
+            if (nt < 11) { tok[nt] = t0; tend[nt] = q; nt++; }
+            else if (q - t0 >= 2 && t0[0] == 'M' && t0[1] == 'D') { mdp = t0; mde = q; }
+        }
+        if (nt < 11) return false;
+        auto set = [&](uint16_t &o, uint16_t &l, int k) { o = (uint16_t)(tok[k] - ls); l = (uint16_t)(tend[k] - tok[k]); };
+        set(r.qn_o, r.qn_l, 0); set(r.rn_o, r.rn_l, 2); set(r.cg_o, r.cg_l, 5); set(r.sq_o, r.sq_l, 9); set(r.ql_o, r.ql_l, 10);
+        if (mdp) { r.md_o = (uint16_t)(mdp - ls); r.md_l = (uint16_t)(mde - mdp); }
+        r.flag = sv_atoi(tok[1], tend[1]); r.pos = sv_atoi(tok[3], tend[3]); r.tlen = sv_atoi(tok[8], tend[8]);
+        const sv rn(tok[2], (size_t)(tend[2] - tok[2]));
+        if (!have_last || rn != last_name) { last_no = names.find(rn); last_name = rn; have_last = true; }
+        r.contigNo = (int32_t)last_no;
+        out.push_back(r);
+    }
+    return true;
+}
+
+struct Fast {
+    State &S; const char *base; const std::vector<RecC> &R;
+    std::vector<std::pair<uint32_t, uint32_t>> emit;       // myout.sam: (record, IH) in file order
+    Fast(State &s, const char *b, const std::vector<RecC> &r) : S(s), base(b), R(r) {}
+    SamV view(size_t i) const {
+        const RecC &r = R[i]; const char *l = base + r.off; SamV v;
+        v.qname = sv(l + r.qn_o, r.qn_l); v.rname = sv(l + r.rn_o, r.rn_l); v.cigar = sv(l + r.cg_o, r.cg_l); v.seq = sv(l + r.sq_o, r.sq_l);
+        v.qual = sv(l + r.ql_o, r.ql_l); v.md = sv(l + r.md_o, r.md_l); v.flag = r.flag; v.pos = r.pos; v.tlen = r.tlen; v.contigNo = r.contigNo;
+        return v;
+    }
+};
+
+char *put_int(char *p, long v);
+void sam_line_v(std::string &dst, const SamV &r, sv seq) {     // writeSam / writeSam2 (:404-417) with the sequence as it stands
+    const size_t at = dst.size();
+    dst.resize(at + r.qname.size() + r.cigar.size() + seq.size() + r.qual.size() + r.md.size() + 96);
+    char *w = &dst[at];
+    memcpy(w, r.qname.data(), r.qname.size()); w += r.qname.size(); *w++ = '\t';
+    w = put_int(w, r.flag); *w++ = '\t'; w = put_int(w, r.contigNo); *w++ = '\t'; w = put_int(w, r.pos); *w++ = '\t';
+    memcpy(w, r.cigar.data(), r.cigar.size()); w += r.cigar.size(); *w++ = '\t';
+    w = put_int(w, r.tlen); *w++ = '\t';
+    memcpy(w, seq.data(), seq.size()); w += seq.size(); *w++ = '\t';
+    memcpy(w, r.qual.data(), r.qual.size()); w += r.qual.size(); *w++ = '\t';
+    memcpy(w, r.md.data(), r.md.size()); w += r.md.size();
+    memcpy(w, "\tIH:i:", 6); w += 6; w = put_int(w, r.ih); *w++ = '\n';
+    dst.resize((size_t)(w - &dst[0]));
+}
+
+char *put_int(char *p, long v) {                     // decimal, as %ld prints it
+    char t[24]; int n = 0; unsigned long u = v < 0 ? (unsigned long)(-(v + 1)) + 1ul : (unsigned long)v;
+    do { t[n++] = (char)('0' + u % 10); u /= 10; } while (u);
+    if (v < 0) *p++ = '-';
+    while (n) *p++ = t[--n];
+    return p;
+}
+
+double n_frac_v(sv s) { int c = 0; for (char ch : s) if (ch == 'N' || ch == 'n') c++; return c / (double)s.size(); }
+
+// what account_myout_line reads back from the line myout_line has just written (processMapping, :1768-1830)
+void account_fields(State &S, const SamV &r) {
+    const long nh = r.ih;
+    // (the re-read scans the tokens behind the sequence for "MD" / "IH" prefixes, the quality string included: a quality string
+    //  that starts with "MD" stands in for a missing MD tag; the real IH token comes last and wins)
+    const sv md = !r.md.empty() ? r.md : ((r.qual.size() >= 2 && r.qual[0] == 'M' && r.qual[1] == 'D') ? r.qual : sv());
+    if (nh == 1 && !(md.size() > 5 && md[5] == '^')) {
+        const long c = r.contigNo;
+        if (c >= 0 && c < (long)S.contigs.size() && !S.contigs[(size_t)c].empty()) {
+            const int insertSize = r.tlen;
+            if (insertSize > 0) { if (insertSize < kMaxFragment) S.insertCounts[(size_t)insertSize]++; else if (insertSize > kMaxFragment) S.discarded++; }
+        }
+    }
+}
+
+void print_vectors_v(Fast &F, std::vector<uint32_t> &reads1, std::vector<uint32_t> &reads2) {     // printVectors, :641-855
+    State &S = F.S;
+    const unsigned long ih = reads1.size();
+    for (unsigned long i = 0; i < ih; i++) {
+        SamV r1 = F.view(reads1[i]), r2 = F.view(reads2[i]);
+        if (r1.rname == "*" || r2.rname == "*") {
+            if (r1.seq.size() > S.maxReadLength) S.maxReadLength = r1.seq.size();
+            if (r2.seq.size() > S.maxReadLength) S.maxReadLength = r2.seq.size();
+            if (n_frac_v(r1.seq) < 0.8 && n_frac_v(r2.seq) < 0.8) { S.unCount++; S.totalCount++; reads1.clear(); reads2.clear(); return; }
+        } else if (r1.rname != r2.rname) {
+        } else {
+            if (r1.seq.size() > S.maxReadLength) S.maxReadLength = r1.seq.size();
+            if (r2.seq.size() > S.maxReadLength) S.maxReadLength = r2.seq.size();
+            r1.ih = (long)ih; r2.ih = (long)ih;
+            F.emit.emplace_back(reads1[i], (uint32_t)ih); F.emit.emplace_back(reads2[i], (uint32_t)ih);
+            if (S.account) { account_fields(S, r1); account_fields(S, r2); }
+        }
+    }
+    S.totalCount++;
+    reads1.clear(); reads2.clear();
+}
+
+void collect_partial_v(State &S, const SamV &read, int pos2) {          // collectPartialSAM :1667-1694
+    const int strandNo = (read.flag & 16) >> 4;
+    const std::string cigar(read.cigar);
+    const int del = parse_del(cigar);
+    const int g = check_pos2(S, read.contigNo, read.pos, (int)read.seq.size(), del);
+    if (g >= 0 && S.partial_read_count[g] <= kReadCap) {
+        const std::string seq(read.seq);
+        if (ncount_ok(seq) && !S.partial_set[g].count(seq)) {
+            Sam tmp; tmp.seq = seq; tmp.cigar = cigar; tmp.pos = read.pos; tmp.qual = std::string(read.qual);
+            write_partial(S, tmp, g, strandNo, del, pos2);
+            S.partial_set[g].insert(seq);
+            S.partial_read_count[g]++;
+            check_mim(S, cigar, g);
+        }
+    }
+}
+
+void print_mixed_v(Fast &F, std::vector<uint32_t> &x1, std::vector<uint32_t> &x2) {              // printMixedVectors, :999-1489
+    State &S = F.S;
+    const int maxD = S.a.maxDistance, samflag = S.a.samflag;
+    for (size_t oi = 0; oi < x1.size(); oi++) {
+        for (size_t oj = 0; oj < x2.size(); oj++) {
+            const SamV read1 = F.view(x1[oi]), read2 = F.view(x2[oj]);
+            if (oi == 0 && oj == 0) {
+                if (read1.seq.size() > S.maxReadLength) S.maxReadLength = read1.seq.size();
+                if (read2.seq.size() > S.maxReadLength) S.maxReadLength = read2.seq.size();
+                if (n_frac_v(read1.seq) < 0.8 && n_frac_v(read2.seq) < 0.8) { S.unCount++; S.totalCount++; }
+                else { x1.clear(); x2.clear(); return; }
+            }
+            if ((read1.flag & 4) != 0 && (read2.flag & 4) != 0) { x1.clear(); x2.clear(); return; }
+            if (((read1.flag & 4) == 0 && (read2.flag & 4) != 0) || ((read1.flag & 4) == 0 && (read2.flag & 4) == 0 && maxD > 250)) {
+                const bool r2_unmapped = (read2.flag & 4) != 0;
+                const SamV m2 = F.view(x2[0]);
+                std::string m2seq(m2.seq);                              // m2[0].seq is rewritten as mates are stored (:1236, :1290)
+                for (size_t i = 0; i < x1.size(); i++) {
+                    const SamV m1 = F.view(x1[i]);
+                    std::string m1seq(m1.seq);
+                    const long contigNo1 = m1.contigNo; const long pos1 = m1.pos; const int strandNo1 = (m1.flag & 16) >> 4;
+                    if (samflag == 2 && !check_char(m2seq)) {
+                        if (r2_unmapped) {
+                            const int g = check_pos(S, contigNo1, pos1, strandNo1, (int)m2seq.size());
+                            if (g >= 0 && S.read_count[g] <= kReadCap) {
+                                const std::string temp = revcomp(m2seq);
+                                if ((strandNo1 == 1 && !dup_jump(S, m2seq, g)) || (strandNo1 == 0 && !dup_jump(S, temp, g))) {
+                                    sam_line_v(S.gap_text[g], m1, m1seq); sam_line_v(S.gap_text[g], m2, m2seq);
+                                    if (strandNo1 == 0) m2seq = temp;
+                                    store_jump(S, g, m2seq);
+                                }
+                            }
+                        } else {
+                            const std::string original2 = m2seq, original1 = m1seq;
+                            const long contigNo2 = m2.contigNo; const long pos2 = m2.pos; const int strandNo2 = (m2.flag & 16) >> 4;
+                            int g = check_pos(S, contigNo1, pos1, strandNo1, (int)m2seq.size());
+                            if (g >= 0 && S.read_count[g] <= kReadCap) {
+                                const std::string temp = revcomp(m2seq);
+                                if (strandNo2 == 1) m2seq = temp;
+                                const std::string rev = revcomp(m2seq);
+                                if ((strandNo1 == 1 && !dup_jump(S, m2seq, g)) || (strandNo1 == 0 && !dup_jump(S, rev, g))) {
+                                    sam_line_v(S.gap_text[g], m1, m1seq); sam_line_v(S.gap_text[g], m2, m2seq);
+                                    if (strandNo1 == 0) m2seq = rev;
+                                    store_jump(S, g, m2seq);
+                                }
+                            }
+                            m2seq = original2; m1seq = original1;
+                            g = check_pos(S, contigNo2, pos2, strandNo2, (int)m1seq.size());
+                            if (g >= 0 && S.read_count[g] <= kReadCap) {
+                                const std::string temp = revcomp(m1seq);
+                                if (strandNo1 == 1) m1seq = temp;
+                                const std::string rev = revcomp(m1seq);
+                                if ((strandNo2 == 1 && !dup_jump(S, m1seq, g)) || (strandNo2 == 0 && !dup_jump(S, rev, g))) {
+                                    sam_line_v(S.gap_text[g], m2, m2seq); sam_line_v(S.gap_text[g], m1, m1seq);
+                                    if (strandNo2 == 0) m1seq = rev;
+                                    store_jump(S, g, m1seq);
+                                }
+                            }
+                            // (m1[i].seq keeps what the last branch left in it; nothing reads it again: the vectors are cleared below)
+                        }
+                    }
+                    if (samflag == 1) collect_partial_v(S, m1, -1);
+                }
+                x1.clear(); x2.clear();
+                return;
+            }
+        }
+    }
+    x1.clear(); x2.clear();
+}
+
+// ---- the whole stage on the parsed records; returns -1 when the input needs the legacy form
+int preprocess_fast(State &S, const Args &a, FILE *myout_file, bool &myout_failed) {
+    const bool jump_far = a.samflag == 2 && a.maxDistance > 250;
+    const bool timing = getenv("FIGSAM_TIMING") != nullptr;                    // stage timers on stderr (tools/time_host_stages.py)
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = tnow();
+    auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[figsam] %-28s %.3f s\n", what, t - t_last); t_last = t; } };
+    int fd = open(a.mapFile.c_str(), O_RDONLY);
+    if (fd < 0) return -1;
+    struct stat stt;
+    if (fstat(fd, &stt) != 0 || stt.st_size == 0) { close(fd); return -1; }
+    const size_t fsz = (size_t)stt.st_size;
+    const char *base = (const char *)mmap(nullptr, fsz, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return -1;
+    NameMap names; names.build(S.contigNames, std::min(S.contigs.size(), S.contigNames.size()));
+    // ---- parallel parse
+    int nthr = (int)std::thread::hardware_concurrency(); if (nthr < 1) nthr = 1; if (nthr > 16) nthr = 16;
+    if (const char *ev = getenv("FIGFILL_THREADS")) { int v = atoi(ev); if (v >= 1 && v <= 64) nthr = v; }
+    if (fsz < (1u << 16)) nthr = 1;
+    std::vector<size_t> cut((size_t)nthr + 1, fsz); cut[0] = 0;
+    for (int t = 1; t < nthr; t++) { size_t p = fsz / (size_t)nthr * (size_t)t; const char *nl = (const char *)memchr(base + p, '\n', fsz - p); cut[(size_t)t] = nl ? (size_t)(nl - base) + 1 : fsz; }
+    std::vector<std::vector<RecC>> parts((size_t)nthr); std::vector<char> okv((size_t)nthr, 1), sawv((size_t)nthr, 0), hasv((size_t)nthr, 0), hdrv((size_t)nthr, 0);
+    {
+        std::vector<std::thread> th;
+        for (int t = 0; t < nthr; t++) th.emplace_back([&, t] {
+            bool saw = false, has = false, hdr = false;
+            parts[(size_t)t].reserve((cut[(size_t)t + 1] - cut[(size_t)t]) / 200 + 16);
+            okv[(size_t)t] = parse_chunk(base, cut[(size_t)t], cut[(size_t)t + 1], names, parts[(size_t)t], saw, has, hdr) ? 1 : 0;
+            sawv[(size_t)t] = saw; hasv[(size_t)t] = has; hdrv[(size_t)t] = hdr; });
+        for (auto &t : th) t.join();
+    }
+    lap("map + parallel parse");
+    bool ok = true, saw = false;                       // header lines only in front of the first record (the loops skip '@' lines at their top level only)
+    for (int t = 0; t < nthr && ok; t++) {
+        if (!okv[(size_t)t] || hdrv[(size_t)t] || (saw && hasv[(size_t)t])) ok = false;
+        if (sawv[(size_t)t]) saw = true;
+    }
+    if (!ok) { munmap((void *)base, fsz); return -1; }
+    std::vector<RecC> R;
+    { size_t n = 0; for (auto &v : parts) n += v.size(); R.reserve(n); for (auto &v : parts) { R.insert(R.end(), v.begin(), v.end()); std::vector<RecC>().swap(v); } }
+    if (R.size() >= 0xffffffffull) { munmap((void *)base, fsz); return -1; }
+    lap("concatenate records");
+    Fast F(S, base, R);
+    const size_t NR = R.size();
+    auto qn = [&](size_t i) { const RecC &r = R[i]; return sv(base + r.off + r.qn_o, r.qn_l); };
+    std::vector<uint32_t> reads1, reads2, mixed1, mixed2;
+    sv preq1 = "*", preq2 = "*";
+    if (jump_far) {
+        // ---- first pass (:2278-2435)
+        S.account = true; S.insertCounts.assign((size_t)kMaxFragment, 1); S.discarded = 0;
+        size_t i = 0; bool end = false;
+        while (i < NR) {
+            size_t r1 = i++;
+            while ((R[r1].flag & 2) == 0) {
+                for (int seg_no = 0; seg_no < 2 && !end; seg_no++) {
+                    const sv q = qn(r1); const int seg = R[r1].flag & 192;
+                    while (q == qn(r1) && (R[r1].flag & 192) == seg) { if (i >= NR) { end = true; break; } r1 = i++; }
+                }
+                if (end) break;
+            }
+            if (end) break;
+            if (i >= NR) break;
+            const size_t r2 = i++;
+            if (qn(r1) != preq1 || qn(r2) != preq2) { preq1 = qn(r1); preq2 = qn(r2); print_vectors_v(F, reads1, reads2); }
+            reads1.push_back((uint32_t)r1); reads2.push_back((uint32_t)r2);
+        }
+        print_vectors_v(F, reads1, reads2);
+        S.account = false;
+        long insCount = S.discarded; double sum = 0;
+        for (long k = 0; k < kMaxFragment; k++) { insCount += S.insertCounts[(size_t)k] - 1; sum += k * (S.insertCounts[(size_t)k] - 1); }
+        S.read_mean = (int)(sum / insCount);
+        preq1 = "*"; preq2 = "*";
+        lap("first pass (insert mean)");
+    }
+    // ---- main pass (:2437-2566)
+    {
+        size_t i = 0; bool end = false;
+        while (i < NR) {
+            size_t r1 = i++;
+            while ((R[r1].flag & 2) == 0) {
+                {   const sv q = qn(r1); const int seg = R[r1].flag & 192;
+                    while (q == qn(r1) && (R[r1].flag & 192) == seg) { mixed1.push_back((uint32_t)r1); if (i >= NR) { end = true; break; } r1 = i++; } }
+                if (end) { mixed1.clear(); break; }
+                {   const sv q = qn(r1); const int seg = R[r1].flag & 192;
+                    while (q == qn(r1) && (R[r1].flag & 192) == seg) { mixed2.push_back((uint32_t)r1); if (i >= NR) { end = true; break; } r1 = i++; } }
+                print_mixed_v(F, mixed1, mixed2);
+                if (end) break;
+            }
+            if (end) break;
+            if (i >= NR) break;
+            const size_t r2 = i++;
+            if (qn(r1) != preq1 || qn(r2) != preq2) {
+                preq1 = qn(r1); preq2 = qn(r2);
+                if (!jump_far) print_vectors_v(F, reads1, reads2);
+                if (a.samflag == 1) {
+                    const SamV v1 = F.view(r1), v2 = F.view(r2);
+                    const bool f1 = v1.cigar == "101M", f2 = v2.cigar == "101M";
+                    if (!(f1 && f2)) { collect_partial_v(S, v1, v2.pos); collect_partial_v(S, v2, v1.pos); }
+                }
+                if (!jump_far) { reads1.push_back((uint32_t)r1); reads2.push_back((uint32_t)r2); }
+            } else if (!jump_far) { reads1.push_back((uint32_t)r1); reads2.push_back((uint32_t)r2); }
+        }
+        if (!jump_far) print_vectors_v(F, reads1, reads2);
+    }
+    lap("main pass (binning)");
+    // ---- myout.sam from the notes.  The sizes of the lines are known from the parsed fields, so every block of records has its
+    // place in the file before a byte is formatted: the file is sized once, mapped, and the blocks are formatted straight into
+    // the mapping by all threads (a single stream of write() calls copies ~0.3 GB/s into the page cache on this class of host;
+    // page faults on a shared mapping scale with the threads).  Falls back to buffered writes when the mapping fails.
+    if (myout_file) {
+        const size_t NE = F.emit.size();
+        const size_t per = 1u << 15;                                   // records per block
+        const size_t nblk = (NE + per - 1) / per;
+        auto ndig = [](long v) { size_t n = v < 0 ? 2 : 1; unsigned long u = v < 0 ? (unsigned long)(-(v + 1)) + 1ul : (unsigned long)v; while (u >= 10) { u /= 10; n++; } return n; };
+        auto fmt = [&](size_t e0, size_t e1, char *w) {
+            for (size_t e = e0; e < e1; e++) {
+                const RecC &r = R[F.emit[e].first]; const char *l = base + r.off;
+                memcpy(w, l + r.qn_o, r.qn_l); w += r.qn_l; *w++ = '\t';
+                w = put_int(w, r.flag); *w++ = '\t'; w = put_int(w, r.contigNo); *w++ = '\t'; w = put_int(w, r.pos); *w++ = '\t';
+                memcpy(w, l + r.cg_o, r.cg_l); w += r.cg_l; *w++ = '\t';
+                w = put_int(w, r.tlen); *w++ = '\t';
+                memcpy(w, l + r.sq_o, r.sq_l); w += r.sq_l; *w++ = '\t';
+                memcpy(w, l + r.ql_o, r.ql_l); w += r.ql_l; *w++ = '\t';
+                memcpy(w, l + r.md_o, r.md_l); w += r.md_l;
+                memcpy(w, "\tIH:i:", 6); w += 6; w = put_int(w, (long)F.emit[e].second); *w++ = '\n';
+            }
+            return w;
+        };
+        std::vector<size_t> boff(nblk + 1, 0);
+        {   // sizes of the blocks (parallel), then their offsets
+            std::vector<std::thread> th;
+            for (int t = 0; t < nthr; t++) th.emplace_back([&, t] {
+                for (size_t b = (size_t)t; b < nblk; b += (size_t)nthr) {
+                    const size_t e0 = b * per, e1 = std::min(NE, e0 + per);
+                    size_t n = 0;
+                    for (size_t e = e0; e < e1; e++) {
+                        const RecC &r = R[F.emit[e].first];
+                        n += (size_t)r.qn_l + r.cg_l + r.sq_l + r.ql_l + r.md_l + ndig(r.flag) + ndig(r.contigNo) + ndig(r.pos) + ndig(r.tlen) + ndig((long)F.emit[e].second) + 15;
+                    }
+                    boff[b + 1] = n;
+                } });
+            for (auto &t : th) t.join();
+            for (size_t b = 0; b < nblk; b++) boff[b + 1] += boff[b];
+        }
+        const size_t total = boff[nblk];
+        bool mapped = false;
+        fflush(myout_file);
+        const int ofd = fileno(myout_file);
+        if (total > 0 && ftell(myout_file) == 0 && ofd >= 0 && ftruncate(ofd, (off_t)total) == 0) {
+            // (fopen(..., "w") gave a write-only descriptor: a shared mapping needs read access as well)
+            int rfd = open(a.outFile.c_str(), O_RDWR);
+            char *om = rfd >= 0 ? (char *)mmap(nullptr, total, PROT_READ | PROT_WRITE, MAP_SHARED, rfd, 0) : (char *)MAP_FAILED;
+            if (rfd >= 0) close(rfd);
+            if (om != (char *)MAP_FAILED) {
+                std::vector<std::thread> th;
+                std::vector<char> bad((size_t)nthr, 0);
+                for (int t = 0; t < nthr; t++) th.emplace_back([&, t] {
+                    for (size_t b = (size_t)t; b < nblk; b += (size_t)nthr) {
+                        const size_t e0 = b * per, e1 = std::min(NE, e0 + per);
+                        char *w = fmt(e0, e1, om + boff[b]);
+                        if ((size_t)(w - om) != boff[b + 1]) bad[(size_t)t] = 1;
+                    } });
+                for (auto &t : th) t.join();
+                for (char c : bad) if (c) myout_failed = true;        // (a size formula out of step with the formatter: never observed)
+                munmap(om, total);
+                fseek(myout_file, 0, SEEK_END);
+                mapped = true;
+            } else if (ftruncate(ofd, 0) != 0) myout_failed = true;
+        }
+        if (!mapped) {
+            std::vector<char> buf;
+            for (size_t b = 0; b < nblk; b++) {
+                buf.resize(boff[b + 1] - boff[b]);
+                fmt(b * per, std::min(NE, b * per + per), buf.data());
+                if (fwrite(buf.data(), 1, buf.size(), myout_file) != buf.size()) myout_failed = true;
+            }
+        }
+    }
+    lap("myout.sam format + write");
+    munmap((void *)base, fsz);
+    return 0;
+}
+
 }  // namespace
 
 int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
     State S; S.a = a;
+    const bool timing = getenv("FIGSAM_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_last = tnow();
+    auto lap = [&](const char *what) { if (timing) { const double t = tnow(); fprintf(stderr, "[figsam] %-28s %.3f s\n", what, t - t_last); t_last = t; } };
     // ---- genome reduction: gap ordinal -> contig index of the UNREDUCED genome (:1883-2007)
     std::map<int, int> contignums;
     if (a.genome_reduction == 1) {
@@ -472,8 +941,10 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
                 }
             }
     }
+    lap("scaffold + gaps");
     const size_t ng = S.gaps.size();
-    S.read_count.assign(ng, 0); S.partial_read_count.assign(ng, 0); S.jump_reads.assign(ng, {}); S.jump_set.assign(ng, {}); S.partial_set.assign(ng, {});
+    S.read_count.assign(ng, 0); S.partial_read_count.assign(ng, 0); S.jump_reads.assign(ng, {}); S.partial_set.assign(ng, {});
+    S.jump_win.assign(ng, {}); S.jump_wlen.assign(ng, -1);
     S.gap_text.assign(ng, ""); S.partial_text.assign(ng, ""); S.perfect_gap.assign(ng, 0); S.perfect_len.assign(ng, 0);
     S.by_contig.assign(S.contigs.size(), {}); S.sorted_contig.assign(S.contigs.size(), 1);
     for (size_t g = 0; g < ng; g++) {
@@ -509,7 +980,18 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
         S.myout_file = fopen(a.outFile.c_str(), "w");
         if (!S.myout_file) { err = "Can't create myout file"; return 1; }
     }
-    if (jump_far) {
+    // the fast form (mapped file, records parsed once in parallel, myout.sam formatted in parallel) unless the input needs the
+    // legacy one below; both produce the same bytes
+    bool fast_done = false;
+    if (!S.writeflag && !getenv("FIGSAM_LEGACY")) {
+        const int frc = preprocess_fast(S, a, S.myout_file, S.myout_failed);
+        if (frc == 0) fast_done = true;
+        else {      // nothing has been written or counted yet unless the parse succeeded: start the legacy form from a clean state
+            S.totalCount = S.unCount = 0; S.maxReadLength = 0; S.read_mean = 0; S.account = false;
+        }
+    }
+    if (fast_done) { fclose(mapFile); mapFile = nullptr; }
+    else if (jump_far) {
         // ---- first pass (:2278-2435): properly paired records -> myout.sam, then the mean insert size read_mean
         // (the reference re-reads the file it has just written, processMapping :1768-1830; here each line is accounted as it is written)
         S.account = true; S.insertCounts.assign((size_t)kMaxFragment, 1); S.discarded = 0;
@@ -543,7 +1025,7 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
         preq1 = "*"; preq2 = "*";
     }
     // ---- main pass (:2437-2566)
-    {
+    if (!fast_done) {
         bool end = false;
         while (next_line()) {
             if (line[0] == '@') continue;
@@ -583,9 +1065,10 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
         }
         if (!jump_far) print_vectors(S, reads1, reads2);
     }
-    fclose(mapFile);
+    if (mapFile) fclose(mapFile);
     if (S.out1) fclose(S.out1);
     if (S.out2) fclose(S.out2);
+    lap("SAM passes (total)");
     // ---- results
     out.gaps = S.gaps; out.perfect_gap = S.perfect_gap; out.perfect_len = S.perfect_len;
     out.totalCount = S.totalCount; out.unCount = S.unCount; out.maxReadLength = S.maxReadLength;
@@ -600,12 +1083,24 @@ int preprocess(const Args &a, Binned &out, std::string &err, int write_mode) {
         std::string st2;
         for (size_t g = 0; g < ng; g++) { snprintf(buf, sizeof buf, "%d\t%d\t%d\n", 1, S.perfect_gap[g], S.perfect_len[g]); st2 += buf; }
         if (!put(a.tmpDir + "stat2.txt", st2)) { err = "can't write stat2.txt"; return 1; }
-        for (size_t g = 0; g < ng && write_mode == 1; g++) {
-            const std::string nm = a.gapsDir + (a.samflag == 2 ? "gaps_" : "partial_gaps_") + std::to_string(g) + ".sam";
-            if (!put(nm, a.samflag == 2 ? S.gap_text[g] : S.partial_text[g])) { err = "can't write " + nm; return 1; }
+        if (write_mode == 1) {
+            // one file per gap (the reference re-opens the gap's file for every read it bins, :404-410): creating ~10^4 files is
+            // what takes the time, so the files are dealt over a few threads
+            int nth = (int)std::thread::hardware_concurrency(); if (nth < 1) nth = 1; if (nth > 8) nth = 8;
+            if (ng < 64) nth = 1;
+            std::vector<long> bad((size_t)nth, -1);
+            std::vector<std::thread> th;
+            for (int t = 0; t < nth; t++) th.emplace_back([&, t] {
+                for (size_t g = (size_t)t; g < ng; g += (size_t)nth) {
+                    const std::string nm = a.gapsDir + (a.samflag == 2 ? "gaps_" : "partial_gaps_") + std::to_string(g) + ".sam";
+                    if (!put(nm, a.samflag == 2 ? S.gap_text[g] : S.partial_text[g]) && bad[(size_t)t] < 0) bad[(size_t)t] = (long)g;
+                } });
+            for (auto &t : th) t.join();
+            for (long g : bad) if (g >= 0) { err = "can't write " + a.gapsDir + (a.samflag == 2 ? "gaps_" : "partial_gaps_") + std::to_string(g) + ".sam"; return 1; }
         }
     }
     out.gap_files = std::move(S.gap_text); out.partial_files = std::move(S.partial_text);
+    lap("run-level + per-gap files");
     return 0;
 }
 

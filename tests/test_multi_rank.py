@@ -253,7 +253,8 @@ def test_bench_starts_its_own_ranks(tmp_path):
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(line) == 1, r.stdout
     d = json.loads(line[0])
-    assert d["n_gpus"] == 2 and d["n_gaps"] == 48 and len(d["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and d["value"] > 0
+    # default scaling is strong: ONE fixed set of 8 x gaps-per-gpu gaps whatever N is, split over the ranks
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["n_gaps"] == 8 * 24 and len(d["roofline"]["per_rank_kernel_ms_per_step"]) == 2 and d["value"] > 0
 
 
 def _cfg4_worker(rank, world, port, workdir, q):

@@ -100,6 +100,29 @@ def test_preprocess_boundary_golden(lib, tmp_path):
     assert n_reads > 50                                     # the fixture really bins reads
 
 
+@pytest.mark.parametrize("seed,threads", [(201, 1), (202, 3), (203, 7)])
+def test_preprocess_fast_and_legacy_forms_agree(seed, threads, tmp_path):
+    """The ingest's fast form (mapped SAM parsed once in parallel chunks, pair logic on the parsed records, myout.sam formatted
+    straight into a mapping of the output file, hash-indexed duplicate test) against the line-by-line legacy form
+    (FIGSAM_LEGACY=1) on fresh synthetic SAMs of both libraries: every output file byte-identical, whatever the chunking."""
+    import shutil
+    from tools import synth_sam
+    src = str(tmp_path / "src")
+    args = synth_sam.make_case(src, seed, n_contigs=1 + seed % 3, end_gap=(seed % 2 == 0), n_frag=700, n_jump=1500)
+    for lib in ("frag", "jump"):
+        outs = {}
+        for form, env in (("fast", {"FIGFILL_THREADS": str(threads)}), ("legacy", {"FIGSAM_LEGACY": "1"})):
+            d = str(tmp_path / f"{lib}_{form}"); shutil.copytree(src, d)
+            a = list(args[lib]); a[-1] = "0"
+            r = util.run([util.FIGTOOL, "preprocess"] + a, d, env)
+            assert r.returncode == 0, r.stderr
+            outs[form] = (_prep_outputs(d), r.stdout)
+        assert sorted(outs["fast"][0]) == sorted(outs["legacy"][0])
+        for k in outs["legacy"][0]:
+            assert outs["fast"][0][k] == outs["legacy"][0][k], (lib, k)
+        assert outs["fast"][1] == outs["legacy"][1]
+
+
 @pytest.mark.skipif(not HAVE_REF, reason="needs the reference binaries (build container only)")
 @pytest.mark.parametrize("seed", [101, 102, 103])
 def test_preprocess_live_against_reference(seed, tmp_path):
