@@ -48,11 +48,17 @@ def main():
     args = ["scf.fa", str(int(jump[0] * 1.15)), "2", "result2.sam", "tmp/myout.sam", "scf.fa", "r_1.fastq", "r_2.fastq", "gaps/", "tmp/", "1", "0", "0"]
     res, times = {}, {}
     stages = ""
-    for who, exe in (("figtool", [TOOL, "preprocess"]), ("reference", [os.path.join(REF, "Preprocess.out")]), ("figtool_again", [TOOL, "preprocess"])):
+    order = [("figtool", [TOOL, "preprocess"]), ("reference", [os.path.join(REF, "Preprocess.out")]), ("figtool_again", [TOOL, "preprocess"])]
+    if n_rec <= 10_000_000:                 # (both sides twice where that is cheap: this container's 8 cores are shared and single runs vary)
+        order.append(("reference_again", [os.path.join(REF, "Preprocess.out")]))
+    for who, exe in order:
         d = os.path.join(base, who); shutil.copytree(src, d, symlinks=True)
         env = dict(os.environ, FIGSAM_TIMING="1")
         t0 = time.time(); r = subprocess.run(exe + args, cwd=d, capture_output=True, text=True, env=env); times[who] = time.time() - t0
         assert r.returncode == 0, r.stderr[-300:]
+        if who == "reference_again":
+            shutil.rmtree(d)
+            continue
         if who == "figtool_again":
             stages = r.stderr
             assert all(filecmp.cmp(os.path.join(d, f), os.path.join(base, "figtool", f), shallow=False) for f in ("tmp/myout.sam", "tmp/stat.txt"))
@@ -62,9 +68,11 @@ def main():
         print(f"[host] N1 {who}: {times[who]:.2f} s = {n_rec / times[who] / 1e3:.0f} k records/s", flush=True)
     same = res["reference"] == res["figtool"]
     best = min(times["figtool"], times["figtool_again"])
+    ref_best = min(times["reference"], times.get("reference_again", times["reference"]))
     line = {"n1_sam_ingest": {"gaps": sum(1 for k in res["figtool"][0] if k.startswith("gaps/gaps_")), "sam_records": n_rec, "reference_s": round(times["reference"], 2),
                               "figtool_s": round(times["figtool"], 2), "figtool_second_run_s": round(times["figtool_again"], 2),
-                              "speedup": round(times["reference"] / times["figtool"], 1), "speedup_best_of_two": round(times["reference"] / best, 1),
+                              "reference_second_run_s": round(times["reference_again"], 2) if "reference_again" in times else None,
+                              "speedup": round(times["reference"] / times["figtool"], 1), "speedup_best_of_two": round(ref_best / best, 1),
                               "outputs_identical": bool(same), "files_compared": len(res["reference"][0]), "work_dir": base,
                               "host_threads": os.cpu_count(), "figtool_stage_timers": [ln.strip() for ln in stages.splitlines() if ln.startswith("[figsam]")]}}
     # ---- N2: the model from the myout.sam the ingest just wrote
