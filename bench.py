@@ -241,7 +241,7 @@ def main():
         "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"synthetic-1e5-gap recipe (SURVEY §8d), {spec.mode}-mode pass, seeded sample of "
                                + (f"{args.gaps_per_gpu} gaps/GPU" if args.scaling == "weak" else f"{n_global} gaps in all (fixed set)") + f" from the {args.mix} gap mix",
-                   "gaps_per_gpu": n_global / world, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
+                   "workload_key": workload_key(args, world), "gaps_per_gpu": n_global / world, "reads_per_gap_mean": float(np.diff(off).mean()), "read_len": spec.read_len,
                    "insert": [spec.insert_mean, spec.insert_sd], "substitution_rate": spec.err,
                    "sharding": f"{n_global} gaps dealt LPT on estimated cost over {world} rank(s), no data-path collective, 1 all-gather of packed results per step"},
     })

@@ -20,9 +20,11 @@
 //   figbird_oracle fillgaps <15 args of FillGaps.cpp main, FillGaps.cpp:419-433>
 // Env: FIG_ORACLE_TRACE=<file> FIG_ORACLE_TRACE_LEVEL=1|2|3|4 -> per-candidate / per-iteration
 //      numeric planes (hex floats) used as kernel-parity fixtures.
+//      FIG_ORACLE_ULP_JITTER=<seed>[:<k>] -> libm sensitivity audit (see lm_jit below); never set by the parity tests.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -564,6 +566,46 @@ static bool build_model() {                                 // Figbird.cpp:7084-
     if (A.partial_flag) { M.insertThresholdMin -= A.partial_len; M.insertThresholdMax += A.partial_len; }
     return true;
 }
+
+// ---- libm sensitivity audit (tools/libm_jitter_audit.py).  The device evaluates log / pow(10, .) / log10 / exp with its own
+// routines (<= 1 ulp from glibc); FIG_ORACLE_ULP_JITTER=<seed>[:<k>[:<permille>]] moves the result of every such call
+// (or of that share of the arguments) by a pseudo-random whole number of ulps in [-k, k] (default k = 1; exact results 0, +-inf and NaN stay), so that a campaign of
+// jittered runs measures whether any decision of the path (base calls, arg-max placements, accept tests, candidate choice)
+// hangs on the last bit of a libm result.  Off unless the variable is set: the oracle's own results never depend on it.
+uint64_t g_jit_state = 0;
+int g_jit_k = 0, g_jit_permille = 1000;
+// The offset is a deterministic function of (seed, call site kind, argument bits): a different libm, not noise -- equal
+// arguments keep equal results, as they do on the device, so exact ties between symmetric candidates stay exact.
+inline double lm_jit(double v, double arg, unsigned kind) {
+    if (!g_jit_k || v == 0.0 || !std::isfinite(v)) return v;
+    uint64_t h; memcpy(&h, &arg, 8);
+    h ^= g_jit_state + 0x9E3779B97F4A7C15ULL * (kind + 1);
+    h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 27; h *= 0x94D049BB133111EBULL; h ^= h >> 31;      // splitmix64 finaliser
+    if (g_jit_permille < 1000 && (int)((h >> 32) % 1000u) >= g_jit_permille) return v;     // only that share of the arguments
+    int d = (int)((h & 0xffffffffu) % (uint64_t)(2 * g_jit_k + 1)) - g_jit_k;
+    for (; d > 0; d--) v = std::nextafter(v, INFINITY);
+    for (; d < 0; d++) v = std::nextafter(v, -INFINITY);
+    return v;
+}
+void lm_jit_init() {
+    const char *e = getenv("FIG_ORACLE_ULP_JITTER");
+    if (!e) return;
+    unsigned long long seed = strtoull(e, nullptr, 10);
+    const char *c = strchr(e, ':');
+    g_jit_k = c ? atoi(c + 1) : 1;
+    const char *c2 = c ? strchr(c + 1, ':') : nullptr;
+    if (c2) g_jit_permille = atoi(c2 + 1);
+    g_jit_state = 0x9E3779B97F4A7C15ULL ^ (seed * 0xD1B54A32D192ED03ULL + 1);
+    if (!g_jit_state) g_jit_state = 1;
+}
+inline double lm_log(double x) { return lm_jit(log(x), x, 0); }
+inline double lm_pow10(double x) { return lm_jit(pow(10, x), x, 1); }
+inline double lm_log10(double x) { return lm_jit(log10(x), x, 2); }
+inline double lm_exp(double x) { return lm_jit(exp(x), x, 3); }
+#define LM_LOG(x) lm_log(x)
+#define LM_POW10(x) lm_pow10(x)
+#define LM_LOG10(x) lm_log10(x)
+#define LM_EXP(x) lm_exp(x)
 
 #include "figbird_oracle_gapfiller.inc"
 

@@ -57,8 +57,9 @@ def main():
         # for the default command the passes above ran
         sys.path.insert(0, os.path.dirname(here))
         import bench
+        key = (line.get("config") or {}).get("workload_key") or "unmapped|gage|set4096|r1000|s20260101|n1"     # (bench.py's default command)
         side = {"head": os.environ.get("FIG_HEAD", tag), "csrc_sha": bench.csrc_sha(),
-                "unmapped|gage|g512|r1000|s20260101|n1": {"bytes_per_step": traffic["bytes_per_step"], "fetch_bytes_raw": traffic["fetch"]["bytes_per_fill_raw"],
+                key: {"bytes_per_step": traffic["bytes_per_step"], "fetch_bytes_raw": traffic["fetch"]["bytes_per_fill_raw"],
                                                           "write_bytes": traffic["write"]["bytes_per_fill_raw"], "note": traffic["note"]}}
         json.dump(side, open(os.path.join(sm, "traffic_sidecar.json"), "w"), indent=1)
     print(json.dumps(traffic))
