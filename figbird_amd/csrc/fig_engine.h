@@ -96,6 +96,8 @@ typedef const double *fig_cdp;
 typedef double *fig_gdp;
 typedef const double *fig_gcdp;
 typedef const uint32_t *fig_gcu32p;
+typedef const unsigned char *fig_gcu8p;
+typedef const unsigned char *fig_lcu8p;
 #else
 extern __shared__ __attribute__((aligned(16))) double fig_lds[];
 #define FIG_RFL(x) __builtin_amdgcn_readfirstlane(x)
@@ -108,6 +110,8 @@ typedef const double __attribute__((address_space(4))) *fig_cdp;
 typedef double __attribute__((address_space(1))) *fig_gdp;
 typedef const double __attribute__((address_space(1))) *fig_gcdp;
 typedef const uint32_t __attribute__((address_space(1))) *fig_gcu32p;
+typedef const unsigned char __attribute__((address_space(1))) *fig_gcu8p;     // batch byte arrays (flank codes)
+typedef const unsigned char __attribute__((address_space(3))) *fig_lcu8p;     // byte strings behind FigState in LDS (E.gs)
 #endif
 
 // 16-byte aligned so that the hot loop fetches a {P,Q} pair with ONE ds_read_b128 (256 B/clk/CU);
@@ -305,11 +309,11 @@ FIG_D int fig_read_code(const uint32_t *packed, long long woff, int len, int j) 
 
 FIG_D int fig_flank_l(const FigEng &E, int k) {      // base at gapStart-k, k >= 1
     if (k > FIG_FLANK) return 4;
-    return E.B->flank[E.g->flankOff + (k - 1)];
+    return ((fig_gcu8p)E.B->flank)[E.g->flankOff + (k - 1)];
 }
 FIG_D int fig_flank_r(const FigEng &E, int k) {      // base at gapStart+G0+k, k >= 0
     if (k >= FIG_FLANK) return 4;
-    return E.B->flank[E.g->flankOff + FIG_FLANK + k];
+    return ((fig_gcu8p)E.B->flank)[E.g->flankOff + FIG_FLANK + k];
 }
 
 // Stage read (unmapped u / partial p) into LDS as byte codes.  Caller syncs afterwards.
@@ -412,7 +416,7 @@ FIG_D int fig_col_kind(const FigEng &E, int x, int G, int left, int right) {
 // charCode of gapString[index] for the MLE pass (Figbird.cpp:3765); outside the string -> 4.
 FIG_D int fig_from_code(const FigEng &E, int x, int G, int left, int right) {
     if (x < 0) { if (x < -left) return 4; return fig_flank_l(E, -x); }
-    if (x < G) return E.gs[x];
+    if (x < G) return ((fig_lcu8p)E.gs)[x];
     if (x < G + right) return fig_flank_r(E, x - G);
     return 4;
 }

@@ -248,6 +248,15 @@ FIG_D int fig_clamp0_i32(int x, int hi) {
 #define FIG_PT_LW(k) ((uint32_t)__builtin_amdgcn_readlane((int)plv, (k)))
 #endif
 
+// sub-phase timers of the diagnostic build (slots the unmapped path leaves unused in a partial-mode pass)
+#ifdef FIG_PROF
+#define FIG_PT0() unsigned long long _fig_pt = __builtin_readcyclecounter()
+#define FIG_PTICK(E, slot) do { unsigned long long _n = __builtin_readcyclecounter(); (E).prof[slot] += _n - _fig_pt; _fig_pt = _n; } while (0)
+#else
+#define FIG_PT0() do { } while (0)
+#define FIG_PTICK(E, slot) do { } while (0)
+#endif
+
 // ---- E-step (:3082-3264).  maxLikelihood is meaningful in thread 0.  TS = 64-column tiles per side (64 TS >= L - 1).
 template <bool LDS, int TS>
 FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc_, double &maxLikelihood_out, unsigned long long &pfl_out) {
@@ -283,6 +292,7 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
         const int nr = nproc - c0 < K ? nproc - c0 : K;
         // ---- phase A
         for (int t = wave; t < nr; t += nw) {
+            FIG_PT0();
             const int p = c0 + t;
             const int len = U.len[pb + p], flag1 = U.aux[pb + p];
             const long long woff = U.woff[pb + p];
@@ -303,18 +313,22 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
                 }
 #endif
                 if (lane == 0) { row[0] = 0.0; row[n + 1] = 0.0; }
+                FIG_PTICK(E, 9);
                 for (int ob = lo; ob <= hi; ob += 2 * wsz) {
                     const int oa = ob + lane, oc = oa + wsz;
                     const bool va = oa <= hi, vc = oc <= hi;
                     double pa = 1.0, pc = 1.0;
                     fig_pchain_e2<LDS>(PQ, ncolE, pk, ktf, j0, j1, (va ? oa : lo) + xoff, (vc ? oc : lo) + xoff, pa, pc);
+                    FIG_PTICK(E, 10);
                     double px[2] = {pa, pc}, tx[2], wx[2];
                     fig_pweights<2>(px, tx, wx);
                     const double ta = tx[0], tc = tx[1], wa = wx[0], wc = wx[1];
                     if (va) { row[1 + oa - lo] = wa; if (ta > best.v) { best.v = ta; best.o = oa; } pfl += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(oa, len, G); }
                     if (vc) { row[1 + oc - lo] = wc; if (tc > best.v) { best.v = tc; best.o = oc; } pfl += 4ULL * (unsigned long long)(j1 - j0) + (unsigned long long)fig_ovl(oc, len, G); }
+                    FIG_PTICK(E, 22);
                 }
                 best = fig_wave_best(E, best);
+                FIG_PTICK(E, 23);
             }
             if (lane == 0) {
                 SL->tm_lo[t] = lo; SL->tm_hi[t] = hi; SL->tm_len[t] = len;
@@ -342,6 +356,7 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
 #else
         {
             for (int t = 0; t < nr; t++) {
+                FIG_PT0();
                 const int lo = fig_u(SL->tm_lo[t]), hi = fig_u(SL->tm_hi[t]), len = fig_u(SL->tm_len[t]);
                 const int n = hi - lo + 1;
                 if (n <= 0) continue;
@@ -358,6 +373,7 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
                 // split into a left and a right region); per (position, tile): one subtract, one v_med3 that clamps the row index
                 // into [zero slot 0, zero slot n + 1], the ds_read_b64 and the add
                 const double *row0 = W + (long long)t * rstride;               // zero slot 0; weights at 1 .. n; zero slot n + 1
+                FIG_PTICK(E, 24);
 #pragma unroll
                 for (int q = 0; q < 2 * TS; q++) {
                     const int xb0 = q < TS ? 64 * q : xr0 + 64 * (q - TS);
@@ -380,6 +396,7 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
                     }
                     acc[q] = a;
                 }
+                FIG_PTICK(E, 25);
             }
         }
 #endif
@@ -446,6 +463,7 @@ FIG_NOINLINE FIG_D void fig_partial_mle(FigEng &E, int gapoffset_, int nproc_, u
     const int ncolE = U.ncolE, xoff = U.xoff;
     unsigned long long pfl = 0;
     for (int p = wave; p < nproc; p += nw) {
+        FIG_PT0();
         const int len = U.len[pb + p], flag1 = U.aux[pb + p];
         const long long woff = U.woff[pb + p];
         const bool leftside = flag1 == 1 || flag1 == 4;
@@ -454,6 +472,7 @@ FIG_NOINLINE FIG_D void fig_partial_mle(FigEng &E, int gapoffset_, int nproc_, u
         fig_window_partial_u(U, U.pos[pb + p], U.refpos[pb + p], len, gapoffset, lo, hi);
         const fig_cu32p pk = U.packed_c + woff;
         FigBest best; best.v = -FIG_DBL_MAX; best.o = FIG_NOPOS;
+        FIG_PTICK(E, 13);
         for (int ob = lo; ob <= hi; ob += 2 * wsz) {
             const int oa = ob + lane, oc = oa + wsz;
             const bool va = oa <= hi, vc = oc <= hi;
@@ -462,6 +481,7 @@ FIG_NOINLINE FIG_D void fig_partial_mle(FigEng &E, int gapoffset_, int nproc_, u
             if (va) { if (qa > best.v) { best.v = qa; best.o = oa; } pfl += (unsigned long long)(j1 - j0); }
             if (vc) { if (qc > best.v) { best.v = qc; best.o = oc; } pfl += (unsigned long long)(j1 - j0); }
         }
+        FIG_PTICK(E, 14);
         best = fig_wave_best(E, best);
         if (lane == 0 && p < prc) {
             const int o = best.o == FIG_NOPOS ? -left : best.o;
@@ -472,6 +492,7 @@ FIG_NOINLINE FIG_D void fig_partial_mle(FigEng &E, int gapoffset_, int nproc_, u
                 if (G == G0) { U.ppos_org[p * 3] = 1; U.ppos_org[p * 3 + 1] = o; U.ppos_org[p * 3 + 2] = len; }
             } else { fig_atomic_add_i32(&E.S->invalid_count, 1); U.pflag[p * 2] = 0; }
         }
+        FIG_PTICK(E, 15);
     }
     pfl_out += pfl; pml_out += pfl;
 }

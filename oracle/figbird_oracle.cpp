@@ -582,10 +582,11 @@ inline double lm_jit(double v, double arg, unsigned kind) {
     h ^= g_jit_state + 0x9E3779B97F4A7C15ULL * (kind + 1);
     h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ULL; h ^= h >> 27; h *= 0x94D049BB133111EBULL; h ^= h >> 31;      // splitmix64 finaliser
     if (g_jit_permille < 1000 && (int)((h >> 32) % 1000u) >= g_jit_permille) return v;     // only that share of the arguments
-    int d = (int)((h & 0xffffffffu) % (uint64_t)(2 * g_jit_k + 1)) - g_jit_k;
-    for (; d > 0; d--) v = std::nextafter(v, INFINITY);
-    for (; d < 0; d++) v = std::nextafter(v, -INFINITY);
-    return v;
+    const int64_t d = (int64_t)((h & 0xffffffffu) % (uint64_t)(2 * (int64_t)g_jit_k + 1)) - g_jit_k;
+    int64_t b; memcpy(&b, &v, 8);                 // finite and nonzero: d ulps away from zero (d > 0) or towards it, whatever the sign
+    b += d;
+    double r; memcpy(&r, &b, 8);
+    return std::isfinite(r) && r != 0.0 ? r : v;
 }
 void lm_jit_init() {
     const char *e = getenv("FIG_ORACLE_ULP_JITTER");

@@ -44,7 +44,7 @@ if __name__ == "__main__":
         filled = res.filled_bases
         reps_was, reps = reps, n_here
         print(json.dumps({"G": G, "gaps": reps, "reads_per_gap": nr / reps, "gen_s": round(tg, 2), "upload_s": round(tu, 3), "fill_s": round(tf, 3),
-                          "kernel_ms": round(st["kernel_ms"], 2), "place_calls": st["place_calls"], "gflop": round(st["alg_flops"] / 1e9, 2),
+                          "kernel_ms": round(st["kernel_ms"], 2), "place_calls": st["place_calls"], "gflop": round(st["alg_flops"] / 1e9, 2), "spec_gflop": round(st["spec_flops"] / 1e9, 2),
                           "tflops": round(st["alg_flops"] / 1e12 / max(st["kernel_ms"] / 1e3, 1e-9), 3), "gaps_per_s": round(reps / max(st["kernel_ms"] / 1e3, 1e-9), 2),
                           "filled": filled, "mism": mism, "lens": [int(x) for x in res.filled_len[:4]]}), flush=True)
         reps = reps_was
