@@ -370,6 +370,22 @@ def main():
         cb["value"] = n_global / mix_s
         cb["value_note"] = ("same-mix extrapolation: this step's algorithmic flops / the reference's measured flop rate on the sample "
                             f"= {mix_s:.0f} s per step on {cb['cores']} cores; measured_sample_gaps_per_s is the raw sample figure (cheapest bracket only)")
+        # the <=400-bp bracket holds ~96 % of the step's flops and cannot be sampled inside this run (10^2-10^3 CPU-seconds per gap):
+        # its per-core flop rate comes from the committed offline measurement (tools/time_reference_small_gaps.py), when there is one
+        small = read_small_gap_rate()
+        if small and cb.get("kind") == "reference":
+            G_all = np.asarray(gbatch.gap_len)
+            share_gt = float(cost[G_all > 400].sum() / max(cost.sum(), 1e-30)) if spec.mode == "unmapped" else 0.0
+            rate_small = small["gflops_one_core_flop_weighted"] * cb["cores"] * 1e9
+            mix2 = (flops_all / steps) * (share_gt / (cb["gflops"] * 1e9) + (1.0 - share_gt) / rate_small)
+            cb["value_sampled_bracket_only"] = cb["value"]
+            cb["value"] = n_global / mix2
+            cb["dominant_bracket"] = {"gflops_one_core": small["gflops_one_core_flop_weighted"], "source": small["source"], "gaps": small["gaps"],
+                                      "flop_share_of_gt400bp_gaps_est": share_gt}
+            cb["value_note"] = (f"same-mix extrapolation: this step's algorithmic flops, {100 * (1 - share_gt):.0f} % of them priced at the reference's flop rate on "
+                                f"<=400-bp bench-regime gaps ({small['gflops_one_core_flop_weighted']:.2f} GFLOP/s per core, measured offline on {len(small['gaps'])} gaps, x {cb['cores']} cores) "
+                                f"and the rest at the rate measured in this run on the >400-bp sample = {mix2:.0f} s per step; "
+                                "measured_sample_gaps_per_s is the raw sample figure (cheapest bracket only)")
     eng.free_batch()
     eng.close()
     shutil.rmtree(work, ignore_errors=True)
@@ -435,6 +451,21 @@ def csrc_sha():
         if fn.endswith((".h", ".hip")):
             h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
     return h.hexdigest()[:12]
+
+
+def read_small_gap_rate():
+    """The reference's own flop rate per core on bench-regime gaps of the <=400-bp bracket, measured offline
+    (tools/time_reference_small_gaps.py -> profiles/round4/cpu_reference_le400bp_gaps.json): oracle/_ref/Figbird.out on the
+    committed bench goldens, outputs equal to the goldens'."""
+    path = os.path.join(ROOT, "profiles", "round4", "cpu_reference_le400bp_gaps.json")
+    try:
+        d = json.load(open(path))
+        gaps = [{k: g[k] for k in ("golden", "gap_bp", "reads", "candidate_lengths", "seconds", "gflops_one_core")} for g in d["gaps"] if g.get("rc") == 0 and g.get("gapout_equals_golden")]
+        if not gaps or not d.get("gflops_one_core_flop_weighted"):
+            return None
+        return {"gflops_one_core_flop_weighted": float(d["gflops_one_core_flop_weighted"]), "gaps": gaps, "source": "profiles/round4/cpu_reference_le400bp_gaps.json (not measured in this run)"}
+    except Exception:
+        return None
 
 
 def read_traffic(args, world):

@@ -28,6 +28,7 @@ def main():
         for fn in ("gapout0.txt", "gaptofill0.txt", "draw0.txt"):
             p = os.path.join(root, "tmp", fn)
             if os.path.exists(p): os.remove(p)
+        open(os.path.join(root, "tmp", "gaploads.txt"), "w").write("0\t\n")       # FillGaps.cpp:313-334 for one worker process holding gap 0
         t0 = time.time()
         procs.append((nm, root, m, t0, subprocess.Popen([ref] + m["figbird_argv"], cwd=root, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)))
     ends = {}
