@@ -421,6 +421,16 @@ FIG_D int fig_from_code(const FigEng &E, int x, int G, int left, int right) {
     return 4;
 }
 
+// fig_from_code on hoisted, typed views: fl = the gap's flank codes (global), gs = the gap string (LDS).  The MLE pass packs the
+// consensus of every extended column with it, 16 columns per word: through fig_from_code each of those lookups reloads the
+// descriptor fields behind E.B / E.g with FLAT instructions.
+FIG_D int fig_from_code_u(fig_gcu8p fl, fig_lcu8p gs, int x, int G, int left, int right) {
+    if (x < 0) { if (x < -left) return 4; const int k = -x; return k > FIG_FLANK ? 4 : fl[k - 1]; }
+    if (x < G) return gs[x];
+    if (x < G + right) { const int k = x - G; return k >= FIG_FLANK ? 4 : fl[FIG_FLANK + k]; }
+    return 4;
+}
+
 // ---------------------------------------------------------------------------------------
 // Accessors of the extended table (generic pointers; the hot loops use the typed LDS form).
 #define FIG_PQ(E, b, x) ((E).pq[(long long)(b) * (E).ncolE + (x) + (E).xoff])

@@ -407,9 +407,11 @@ FIG_D void fig_build_mle_table(FigEng &E, int G, int left, int right) {
     double *C = (double *)E.pq;
     int n = G + 2 * E.xoff;
     if (n > E.ncolE) n = E.ncolE;
+    const fig_gcu8p fl = (fig_gcu8p)fig_uptr(E.B)->flank + fig_u64(fig_uptr(E.g)->flankOff);
+    const fig_lcu8p gsl = (fig_lcu8p)E.gs;
     for (int i = E.tid; i < n; i += E.nt) {
         int x = i - E.xoff;
-        int from = fig_from_code(E, x, G, left, right);
+        int from = fig_from_code_u(fl, gsl, x, G, left, right);
         for (int to = 0; to < 5; to++) C[(long long)to * E.ncolE + i] = (from == to) ? -1.0 : T[from * 5 + to];
     }
     FIG_SYNC();
@@ -995,11 +997,13 @@ FIG_D void fig_hot_mle(FigEng &E, int gapoffset, int mode, int gl, int wl, int w
     uint32_t *kc = (uint32_t *)(fig_w_ptr<LDS>(E) + fb_doubles + nci_doubles), *kn = kc + kwords;
     if (use_kf) {
         int ncb = gl + 2 * xoff; if (ncb > ncolE) ncb = ncolE;
+        const fig_gcu8p fl = (fig_gcu8p)fig_uptr(E.B)->flank + fig_u64(fig_uptr(E.g)->flankOff);
+        const fig_lcu8p gsl = (fig_lcu8p)E.gs;
         for (int wd = E.tid; wd < kwords; wd += E.nt) {
             uint32_t c2 = 0, n2 = 0;
             for (int q = 0; q < 16; q++) {
                 const int i = wd * 16 + q;
-                const int from = i < ncb ? fig_from_code(E, i - xoff, gl, wl, wr) : 4;
+                const int from = i < ncb ? fig_from_code_u(fl, gsl, i - xoff, gl, wl, wr) : 4;
                 if (from >= 0 && from < 4) c2 |= (uint32_t)from << (2 * q); else n2 |= 1u << (2 * q);
             }
             kc[wd] = c2; kn[wd] = n2;

@@ -85,6 +85,15 @@ FIG_D void fig_window_partial_u(const FigPartU &U, int pos1, int ref_pos, int le
     }
 }
 
+// The second placement of a lane is always the first + 64 (o and o + wsz), so both loads of a step share one address register and
+// the second takes the instruction's constant offset (fig_eblk_load's DX form); a lane whose second placement lies outside the
+// window reads at most 64 columns past it -- inside the table area, result ignored.  (One emulated lane: wsz = 1, plain form.)
+#ifdef FIG_EMU
+#define FIG_PDX 0
+#else
+#define FIG_PDX 64
+#endif
+
 // steps [a, b) of an 8-step block (wave-uniform bounds)
 FIG_D void fig_eblk_compute_r(const FigEBlk &B, int a, int b, double &pa, double &pb) {
 #pragma unroll
@@ -171,21 +180,21 @@ FIG_D void fig_pchain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, i
     if (j1 <= j0) return;
     const int b0 = j0 >> 3, b1 = (j1 - 1) >> 3;
     FigEBlk A, Bk;
-    fig_eblk_load<LDS, 0>(A, PQ, ncolE, pk, kt, b0, xa, xb);
+    fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, b0, xa, xb);
     if (b0 == b1) { fig_eblk_compute_r(A, j0 - 8 * b0, j1 - 8 * b0, pa, pb); return; }
     // first block (may start inside it), full blocks without a branch per step, last block (may end inside it); the loads of
     // block i + 1 go out before the arithmetic of block i
-    fig_eblk_load<LDS, 0>(Bk, PQ, ncolE, pk, kt, b0 + 1, xa, xb);
+    fig_eblk_load<LDS, FIG_PDX>(Bk, PQ, ncolE, pk, kt, b0 + 1, xa, xb);
     fig_eblk_compute_r(A, j0 - 8 * b0, 8, pa, pb);
     int bi = b0 + 1;                                   // block bi is in Bk
     for (; bi + 2 <= b1; bi += 2) {
-        fig_eblk_load<LDS, 0>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+        fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
         fig_eblk_compute(Bk, pa, pb);
-        fig_eblk_load<LDS, 0>(Bk, PQ, ncolE, pk, kt, bi + 2, xa, xb);
+        fig_eblk_load<LDS, FIG_PDX>(Bk, PQ, ncolE, pk, kt, bi + 2, xa, xb);
         fig_eblk_compute(A, pa, pb);
     }
     if (bi + 1 <= b1) {                                // bi full, bi + 1 = b1 last
-        fig_eblk_load<LDS, 0>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
+        fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
         fig_eblk_compute(Bk, pa, pb);
         fig_eblk_compute_r(A, 0, j1 - 8 * b1, pa, pb);
     } else fig_eblk_compute_r(Bk, 0, j1 - 8 * b1, pa, pb);      // bi == b1
@@ -197,19 +206,19 @@ FIG_D void fig_pchain_m2(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, i
     if (j1 <= j0) return;
     const int b0 = j0 >> 3, b1 = (j1 - 1) >> 3;
     FigMBlk A, Bk;
-    fig_mblk_load<LDS, 0>(A, C, ncolE, pk, mt, b0, xa, xb);
+    fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, b0, xa, xb);
     if (b0 == b1) { fig_mblk_compute_r(A, j0 - 8 * b0, j1 - 8 * b0, qa, qb); return; }
-    fig_mblk_load<LDS, 0>(Bk, C, ncolE, pk, mt, b0 + 1, xa, xb);
+    fig_mblk_load<LDS, FIG_PDX>(Bk, C, ncolE, pk, mt, b0 + 1, xa, xb);
     fig_mblk_compute_r(A, j0 - 8 * b0, 8, qa, qb);
     int bi = b0 + 1;
     for (; bi + 2 <= b1; bi += 2) {
-        fig_mblk_load<LDS, 0>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
+        fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
         fig_mblk_compute(Bk, qa, qb);
-        fig_mblk_load<LDS, 0>(Bk, C, ncolE, pk, mt, bi + 2, xa, xb);
+        fig_mblk_load<LDS, FIG_PDX>(Bk, C, ncolE, pk, mt, bi + 2, xa, xb);
         fig_mblk_compute(A, qa, qb);
     }
     if (bi + 1 <= b1) {
-        fig_mblk_load<LDS, 0>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
+        fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
         fig_mblk_compute(Bk, qa, qb);
         fig_mblk_compute_r(A, 0, j1 - 8 * b1, qa, qb);
     } else fig_mblk_compute_r(Bk, 0, j1 - 8 * b1, qa, qb);
