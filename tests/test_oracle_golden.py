@@ -59,3 +59,28 @@ def test_oracle_matches_live_reference_in_the_134_400_bracket(seed, tmp_path):
     from tools.fuzz_ref import mk_mid
     from tools.compare_ref import compare
     assert compare(mk_mid(seed), str(tmp_path), verbose=False)
+
+
+def test_libm_jitter_switch_is_deterministic_and_off_by_default(tmp_path):
+    """The sensitivity audit's switch (oracle/figbird_oracle.cpp: FIG_ORACLE_ULP_JITTER, tools/libm_jitter_audit.py) moves every
+    libm result by an argument-keyed offset: the same seed gives the same bytes, k = 0 is the plain oracle, and a gross offset
+    (10^9 ulps ~ 1e-7 relative) does change the likelihoods in the oracle's trace -- the switch is live where the audit says it
+    is -- while this small case's output bytes survive even that."""
+    import subprocess
+    outs = {}
+    for tag, env in (("plain", None), ("k0", "7:0"), ("k1a", "7:1"), ("k1b", "7:1"), ("gross", "7:1000000000")):
+        root = util.extract_golden("partial_small", str(tmp_path / tag))
+        e = dict(os.environ)
+        e.pop("FIG_ORACLE_ULP_JITTER", None)
+        if env: e["FIG_ORACLE_ULP_JITTER"] = env
+        e["FIG_ORACLE_TRACE"] = os.path.join(root, "o.trace"); e["FIG_ORACLE_TRACE_LEVEL"] = "1"
+        r = subprocess.run([util.ORACLE, "fillgaps"] + util.meta(root)["fillgaps_argv"], cwd=root, capture_output=True, text=True, env=e)
+        assert r.returncode == 0, r.stderr
+        outs[tag] = tuple(util.read(os.path.join(root, "tmp", fn)) for fn in util.ref_files(root))
+        outs[tag + "_trace"] = util.read(os.path.join(root, "o.trace"))
+        if tag == "plain":
+            assert outs[tag] == tuple(util.read(os.path.join(root, "ref", fn)) for fn in util.ref_files(root))
+    assert outs["k0"] == outs["plain"]
+    assert outs["k1a"] == outs["k1b"]
+    assert outs["k0_trace"] == outs["plain_trace"] and outs["k1a_trace"] == outs["k1b_trace"]
+    assert outs["gross_trace"] != outs["plain_trace"]

@@ -34,7 +34,9 @@ def main():
     ends = {}
     while len(ends) < len(procs):                     # every process's own wall time (they run side by side on idle cores)
         for nm, root, m, t0, p in procs:
-            if nm not in ends and p.poll() is not None: ends[nm] = (time.time() - t0, p.returncode)
+            if nm not in ends and p.poll() is not None:
+                ends[nm] = (time.time() - t0, p.returncode)
+                print(f"[done] {nm}: {ends[nm][0]:.1f} s rc {ends[nm][1]}", flush=True)
         time.sleep(0.25)
     res = []
     for nm, root, m, t0, p in procs:
