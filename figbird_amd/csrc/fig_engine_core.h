@@ -204,6 +204,8 @@ FIG_D bool fig_update_partial_prob_cols(FigEng &E, int gaplen) {
         st[(long long)p * RW + 4 + k] = k < nw2 + nwm ? E.B->packed[PR.woff[pb + p] + k] : 0u;
     }
     FIG_SYNC();
+    const int left_max = S.left_max, right_min = S.right_min;
+    const int rstart = right_min + 5 > left_max - 4 ? (right_min + 5 > 0 ? right_min + 5 : 0) : (left_max - 4 > 0 ? left_max - 4 : 0);   // first column of partial_right
     for (int j = E.tid; j < gaplen; j += E.nt) {
         int c0 = 1, c1 = 1, c2 = 1, c3 = 1;
         if (j < cg) {
@@ -229,16 +231,16 @@ FIG_D bool fig_update_partial_prob_cols(FigEng &E, int gaplen) {
         if (c3 > max_val) { max_val = c3; max_index = 3; }
         E.scr.colchar[j] = (unsigned char)max_index;
         FIG_PQ(E, 0, j).p = (double)c0 / total; FIG_PQ(E, 1, j).p = (double)c1 / total; FIG_PQ(E, 2, j).p = (double)c2 / total; FIG_PQ(E, 3, j).p = (double)c3 / total;
+        // partial_left / partial_right (:2062-2079: one pass over the columns, `i <= left_max - 5` -> left, else `i >= right_min + 5`
+        // -> right, 99 characters each at most) are two contiguous column ranges: every column writes its own character
+        if (j <= left_max - 5) { if (j < 99) S.partial_left[j] = (unsigned char)max_index; }
+        else if (j >= right_min + 5) { const int k = j - rstart; if (k < 99) S.partial_right[k] = (unsigned char)max_index; }
     }
-    FIG_SYNC();
-    if (E.tid == 0 && E.M->partial_flag == 1) S.partial_read_count = np;
     if (E.tid == 0) {
-        int lc = 0, rc = 0;
-        for (int i = 0; i < gaplen; i++) {
-            if (i <= S.left_max - 5) { if (lc < 99) S.partial_left[lc++] = E.scr.colchar[i]; }
-            else if (i >= S.right_min + 5) { if (rc < 99) S.partial_right[rc++] = E.scr.colchar[i]; }
-        }
-        S.pl_len = lc; S.pr_len = rc;
+        if (E.M->partial_flag == 1) S.partial_read_count = np;
+        int nl = left_max - 4; if (nl < 0) nl = 0; if (nl > gaplen) nl = gaplen;
+        int nr = gaplen - rstart; if (nr < 0) nr = 0;
+        S.pl_len = nl < 99 ? nl : 99; S.pr_len = nr < 99 ? nr : 99;
     }
     FIG_SYNC();
     return true;

@@ -11,13 +11,13 @@
 //   phase A  every wave takes reads p = wave, wave + nw, ... of a super-chunk of up to FIG_PT_ROWS reads; lanes = placements,
 //            TWO per lane (o and o + 64: a 101-bp read's 100 placements are one round), the pair chain of the unmapped hot
 //            path (fig_eblk_*: read bases and {1-e, e} pairs through scalar loads, one ds_read_b128 per step and placement,
-//            8-step blocks with the next block's loads ahead of the arithmetic); the clipped bases (clip_thresh = 2,
+//            8-step blocks, a lane's two placements on one address register); the clipped bases (clip_thresh = 2,
 //            :3117-3118) are left out by the block's step range; weights w = pow(10, log p) go to the read's LDS row
 //            [0 | w(lo) .. w(hi) | 0], the read's maximum through one DPP reduction;
 //   barrier
 //   phase B  wave b owns base b and adds, for every read of the super-chunk in file order and every position j of base b
 //            in it (the packed record's position lists, descending j = ascending placement), row[x - j] to its register
-//            accumulators, lanes = columns x: the reference's (read, placement) order per (column, base), no atomics.  Only
+//            accumulators (two column tiles of a read side by side), lanes = columns x: the reference's (read, placement) order per (column, base), no atomics.  Only
 //            the columns a partial read can reach have accumulators: x < 64 TS from the left and x >= G - 64 TS from the
 //            right (64 TS >= L - 1); the index is clamped into the row's zero slots instead of padding the row by a tile;
 //   barrier (the rows are reused by the next super-chunk)
@@ -179,25 +179,16 @@ template <bool LDS>
 FIG_D void fig_pchain_e2(const FigPQ *PQ, int ncolE, fig_cu32p pk, fig_cdp kt, int j0, int j1, int xa, int xb, double &pa, double &pb) {
     if (j1 <= j0) return;
     const int b0 = j0 >> 3, b1 = (j1 - 1) >> 3;
-    FigEBlk A, Bk;
-    fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, b0, xa, xb);
-    if (b0 == b1) { fig_eblk_compute_r(A, j0 - 8 * b0, j1 - 8 * b0, pa, pb); return; }
-    // first block (may start inside it), full blocks without a branch per step, last block (may end inside it); the loads of
-    // block i + 1 go out before the arithmetic of block i
-    fig_eblk_load<LDS, FIG_PDX>(Bk, PQ, ncolE, pk, kt, b0 + 1, xa, xb);
-    fig_eblk_compute_r(A, j0 - 8 * b0, 8, pa, pb);
-    int bi = b0 + 1;                                   // block bi is in Bk
-    for (; bi + 2 <= b1; bi += 2) {
-        fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
-        fig_eblk_compute(Bk, pa, pb);
-        fig_eblk_load<LDS, FIG_PDX>(Bk, PQ, ncolE, pk, kt, bi + 2, xa, xb);
-        fig_eblk_compute(A, pa, pb);
+    // One 8-step block at a time: first block (may start inside it), full blocks without a branch per step, last block (may
+    // end inside it).  The two-register-set form of the unmapped pair chain (loads of block i + 1 ahead of the arithmetic of
+    // block i) buys nothing here -- with one wave per SIMD and workgroup the chain is bound by the ~135 instructions a block
+    // issues, two waves sharing the SIMD's vector unit (3 841 against 3 898 gaps/s) -- and costs 64 more VGPRs.
+    for (int bi = b0; bi <= b1; bi++) {
+        FigEBlk A;
+        fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, bi, xa, xb);
+        if (bi == b0 || bi == b1) fig_eblk_compute_r(A, bi == b0 ? j0 - 8 * b0 : 0, bi == b1 ? j1 - 8 * b1 : 8, pa, pb);
+        else fig_eblk_compute(A, pa, pb);
     }
-    if (bi + 1 <= b1) {                                // bi full, bi + 1 = b1 last
-        fig_eblk_load<LDS, FIG_PDX>(A, PQ, ncolE, pk, kt, bi + 1, xa, xb);
-        fig_eblk_compute(Bk, pa, pb);
-        fig_eblk_compute_r(A, 0, j1 - 8 * b1, pa, pb);
-    } else fig_eblk_compute_r(Bk, 0, j1 - 8 * b1, pa, pb);      // bi == b1
 }
 
 // MLE products of two placements over [j0, j1) (Figbird.cpp:3383-3407): C[to][x] = -1 on a match, T[from][to] otherwise.
@@ -205,23 +196,12 @@ template <bool LDS>
 FIG_D void fig_pchain_m2(const double *C, int ncolE, fig_cu32p pk, fig_cdp mt, int j0, int j1, int xa, int xb, double &qa, double &qb) {
     if (j1 <= j0) return;
     const int b0 = j0 >> 3, b1 = (j1 - 1) >> 3;
-    FigMBlk A, Bk;
-    fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, b0, xa, xb);
-    if (b0 == b1) { fig_mblk_compute_r(A, j0 - 8 * b0, j1 - 8 * b0, qa, qb); return; }
-    fig_mblk_load<LDS, FIG_PDX>(Bk, C, ncolE, pk, mt, b0 + 1, xa, xb);
-    fig_mblk_compute_r(A, j0 - 8 * b0, 8, qa, qb);
-    int bi = b0 + 1;
-    for (; bi + 2 <= b1; bi += 2) {
-        fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
-        fig_mblk_compute(Bk, qa, qb);
-        fig_mblk_load<LDS, FIG_PDX>(Bk, C, ncolE, pk, mt, bi + 2, xa, xb);
-        fig_mblk_compute(A, qa, qb);
+    for (int bi = b0; bi <= b1; bi++) {
+        FigMBlk A;
+        fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, bi, xa, xb);
+        if (bi == b0 || bi == b1) fig_mblk_compute_r(A, bi == b0 ? j0 - 8 * b0 : 0, bi == b1 ? j1 - 8 * b1 : 8, qa, qb);
+        else fig_mblk_compute(A, qa, qb);
     }
-    if (bi + 1 <= b1) {
-        fig_mblk_load<LDS, FIG_PDX>(A, C, ncolE, pk, mt, bi + 1, xa, xb);
-        fig_mblk_compute(Bk, qa, qb);
-        fig_mblk_compute_r(A, 0, j1 - 8 * b1, qa, qb);
-    } else fig_mblk_compute_r(Bk, 0, j1 - 8 * b1, qa, qb);
 }
 
 // Does the fast form apply to this placeReads call?  (Wave-uniform; the same answer in every thread.)
@@ -383,28 +363,71 @@ FIG_NOINLINE FIG_D void fig_partial_estep_t(FigEng &E, int gapoffset_, int nproc
                 // into [zero slot 0, zero slot n + 1], the ds_read_b64 and the add
                 const double *row0 = W + (long long)t * rstride;               // zero slot 0; weights at 1 .. n; zero slot n + 1
                 FIG_PTICK(E, 24);
+                // one tile: acc[Q] += row0[clamp(x - j)] over the base's positions, in list order
+#define FIG_PB_TILE1(Q, XB) do { \
+                    const int xl1 = (XB) + lane - lo + 1; \
+                    double a = acc[Q]; \
+                    int k4 = 0; \
+                    for (; 4 * k4 + 4 <= nb; k4++) { \
+                        const uint32_t s4 = FIG_PT_LW(d0 + k4); \
+                        const int i0 = fig_clamp0_i32(xl1 - (int)(s4 & 255), n + 1), i1 = fig_clamp0_i32(xl1 - (int)((s4 >> 8) & 255), n + 1); \
+                        const int i2 = fig_clamp0_i32(xl1 - (int)((s4 >> 16) & 255), n + 1), i3 = fig_clamp0_i32(xl1 - (int)(s4 >> 24), n + 1); \
+                        const double v0 = row0[i0], v1 = row0[i1], v2 = row0[i2], v3 = row0[i3]; \
+                        a += v0; a += v1; a += v2; a += v3; \
+                    } \
+                    const int rem = nb - 4 * k4; \
+                    if (rem > 0) { \
+                        const uint32_t s4 = FIG_PT_LW(d0 + k4); \
+                        for (int k = 0; k < rem; k++) a += row0[fig_clamp0_i32(xl1 - (int)((s4 >> (8 * k)) & 255), n + 1)]; \
+                    } \
+                    acc[Q] = a; } while (0)
+                // two tiles side by side: one pass over the position list, eight loads in flight, two independent add chains (one
+                // tile at a time a lone wave sits out a load round trip and four dependent adds per group of four positions).
+                // Written as macros on acc[constant]: through lambdas the accumulators lose their registers.  (Issuing group g + 1's
+                // loads ahead of group g's adds over two register sets -- the compiler then interleaves them with counted waits --
+                // is SLOWER: 3 431 against 3 841 gaps/s.)
+#define FIG_PB_TILE2(QA, QB, XBA, XBB) do { \
+                    const int xA = (XBA) + lane - lo + 1, xB = (XBB) + lane - lo + 1; \
+                    double a = acc[QA], b2 = acc[QB]; \
+                    int k4 = 0; \
+                    for (; 4 * k4 + 4 <= nb; k4++) { \
+                        const uint32_t s4 = FIG_PT_LW(d0 + k4); \
+                        const int j0_ = (int)(s4 & 255), j1_ = (int)((s4 >> 8) & 255), j2_ = (int)((s4 >> 16) & 255), j3_ = (int)(s4 >> 24); \
+                        const double u0 = row0[fig_clamp0_i32(xA - j0_, n + 1)], w0 = row0[fig_clamp0_i32(xB - j0_, n + 1)]; \
+                        const double u1 = row0[fig_clamp0_i32(xA - j1_, n + 1)], w1 = row0[fig_clamp0_i32(xB - j1_, n + 1)]; \
+                        const double u2 = row0[fig_clamp0_i32(xA - j2_, n + 1)], w2 = row0[fig_clamp0_i32(xB - j2_, n + 1)]; \
+                        const double u3 = row0[fig_clamp0_i32(xA - j3_, n + 1)], w3 = row0[fig_clamp0_i32(xB - j3_, n + 1)]; \
+                        a += u0; b2 += w0; a += u1; b2 += w1; a += u2; b2 += w2; a += u3; b2 += w3; \
+                    } \
+                    const int rem = nb - 4 * k4; \
+                    if (rem > 0) { \
+                        const uint32_t s4 = FIG_PT_LW(d0 + k4); \
+                        for (int k = 0; k < rem; k++) { \
+                            const int j_ = (int)((s4 >> (8 * k)) & 255); \
+                            const double u = row0[fig_clamp0_i32(xA - j_, n + 1)], w = row0[fig_clamp0_i32(xB - j_, n + 1)]; \
+                            a += u; b2 += w; \
+                        } \
+                    } \
+                    acc[QA] = a; acc[QB] = b2; } while (0)
+                if (ngrp == 1) {
 #pragma unroll
-                for (int q = 0; q < 2 * TS; q++) {
-                    const int xb0 = q < TS ? 64 * q : xr0 + 64 * (q - TS);
-                    const bool mine = ngrp == 1 || (q % ngrp) == grp;
-                    if (!(mine && xb0 <= xz && xb0 + 63 >= xa && xb0 < G)) continue;      // (wave-uniform)
-                    const int xl1 = xb0 + lane - lo + 1;
-                    double a = acc[q];
-                    int k4 = 0;
-                    for (; 4 * k4 + 4 <= nb; k4++) {
-                        const uint32_t s4 = FIG_PT_LW(d0 + k4);
-                        const int i0 = fig_clamp0_i32(xl1 - (int)(s4 & 255), n + 1), i1 = fig_clamp0_i32(xl1 - (int)((s4 >> 8) & 255), n + 1);
-                        const int i2 = fig_clamp0_i32(xl1 - (int)((s4 >> 16) & 255), n + 1), i3 = fig_clamp0_i32(xl1 - (int)(s4 >> 24), n + 1);
-                        const double v0 = row0[i0], v1 = row0[i1], v2 = row0[i2], v3 = row0[i3];
-                        a += v0; a += v1; a += v2; a += v3;
+                    for (int q = 0; q < 2 * TS; q += 2) {
+                        const int xbA = q < TS ? 64 * q : xr0 + 64 * (q - TS), xbB = q + 1 < TS ? 64 * (q + 1) : xr0 + 64 * (q + 1 - TS);
+                        const bool onA = xbA <= xz && xbA + 63 >= xa && xbA < G, onB = xbB <= xz && xbB + 63 >= xa && xbB < G;      // (wave-uniform)
+                        if (onA && onB) FIG_PB_TILE2(q, q + 1, xbA, xbB);
+                        else if (onA) FIG_PB_TILE1(q, xbA);
+                        else if (onB) FIG_PB_TILE1(q + 1, xbB);
                     }
-                    const int rem = nb - 4 * k4;
-                    if (rem > 0) {
-                        const uint32_t s4 = FIG_PT_LW(d0 + k4);
-                        for (int k = 0; k < rem; k++) a += row0[fig_clamp0_i32(xl1 - (int)((s4 >> (8 * k)) & 255), n + 1)];
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 2 * TS; q++) {
+                        const int xb0 = q < TS ? 64 * q : xr0 + 64 * (q - TS);
+                        if (!((q % ngrp) == grp && xb0 <= xz && xb0 + 63 >= xa && xb0 < G)) continue;      // (wave-uniform)
+                        FIG_PB_TILE1(q, xb0);
                     }
-                    acc[q] = a;
                 }
+#undef FIG_PB_TILE1
+#undef FIG_PB_TILE2
                 FIG_PTICK(E, 25);
             }
         }
@@ -518,7 +541,7 @@ template <bool LDS>
 FIG_D void fig_detect_overlap_par(FigEng &E, const int *pflag, int stride, int gaplen, int *ret_v, int len_thresh) {
     FigState &S = *E.S;
     const int prc = S.partial_read_count, np = E.g->nP;
-    const int rl = (E.M->L + 7) & ~7;
+    const int rl = (E.M->L + 15) & ~15;                 // bytes per staged read: whole packed words (16 bases each)
     const long long cap_bytes = (long long)E.ncolE * 72;
     if (!LDS || !E.pq_lds || E.tiles > 0 || prc > 192 || (long long)prc * rl > cap_bytes || np < prc) {
         if (E.tid == 0) fig_detect_overlap(E, pflag, stride, gaplen, ret_v, len_thresh);
@@ -531,10 +554,28 @@ FIG_D void fig_detect_overlap_par(FigEng &E, const int *pflag, int stride, int g
     // stage the reads (the MLE table in this area is dead: the next computeProbsGap rebuilds {P,Q})
     FIG_SYNC();
     if (E.tid == 0) { S.ibuf[0] = -FIG_MAX_GAP; S.ibuf[1] = FIG_MAX_GAP; S.ibuf[2] = 0; S.ibuf[3] = 0; S.ibuf[4] = 0; S.ibuf[5] = 0x7fffffff; S.ibuf[6] = 0; }
-    for (int i = E.tid; i < prc * rl; i += E.nt) {
-        const int k = i / rl, j = i - k * rl;
-        const int len = PR.len[pb + k];
-        codes[i] = j < len ? (unsigned char)fig_read_code(E.B->packed, PR.woff[pb + k], len, j) : (unsigned char)255;
+    // one packed word (16 bases) per thread and trip: two global loads and four LDS stores per 16 codes (a byte at a time through
+    // fig_read_code was 5 000 trips of three dependent global loads per call)
+    {
+        const int nwr = rl >> 4;
+        uint32_t *codes32 = (uint32_t *)codes;
+        for (int i = E.tid; i < prc * nwr; i += E.nt) {
+            const int k = i / nwr, wi = i - k * nwr;
+            const int len = PR.len[pb + k];
+            const long long woff = PR.woff[pb + k];
+            const int nw2 = (len + 15) >> 4;
+            uint32_t w = 0, m = 0;
+            if (wi < nw2) { w = E.B->packed[woff + wi]; m = (E.B->packed[woff + nw2 + (wi >> 1)] >> ((wi & 1) * 16)) & 0xffffu; }
+            for (int q4 = 0; q4 < 4; q4++) {
+                uint32_t v = 0;
+                for (int q = 0; q < 4; q++) {
+                    const int b = q4 * 4 + q, j = wi * 16 + b;
+                    const uint32_t c = j < len ? (((m >> b) & 1u) ? 4u : ((w >> (2 * b)) & 3u)) : 255u;
+                    v |= c << (8 * q);
+                }
+                codes32[(long long)k * (rl >> 2) + wi * 4 + q4] = v;
+            }
+        }
     }
     FIG_SYNC();
     // ---- l_max / r_min (:2545-2590): the reference's per-base walk in closed form
@@ -582,10 +623,8 @@ FIG_D void fig_detect_overlap_par(FigEng &E, const int *pflag, int stride, int g
     FIG_SYNC();
     const int ovflag = S.ibuf[2];
     if (ovflag || (E.g->stat2 == 1 && E.g->G0 <= 20 && gaplen == E.g->stat3)) {
-        if (E.tid == 0) {
-            for (int k = 0; k < prc; k++) E.scr.smflag[k] = (kind[k] >> 2) & 1;      // as the serial form leaves it
-            ret_v[0] = 300; ret_v[1] = 0;
-        }
+        for (int k = E.tid; k < prc; k += E.nt) E.scr.smflag[k] = (kind[k] >> 2) & 1;      // as the serial form leaves it (every thread: the entries it wrote)
+        if (E.tid == 0) { ret_v[0] = 300; ret_v[1] = 0; }
         FIG_SYNC();
         return;
     }
@@ -628,8 +667,8 @@ FIG_D void fig_detect_overlap_par(FigEng &E, const int *pflag, int stride, int g
         const int max_overlap = S.ibuf[4];
         if (best_len > 0 && best_len == max_overlap) fig_atomic_min_i32(&S.ibuf[5], best_key);
         FIG_SYNC();
+        for (int k = E.tid; k < prc; k += E.nt) E.scr.smflag[k] = (kind[k] >> 2) & 1;
         if (E.tid == 0) {
-            for (int k = 0; k < prc; k++) E.scr.smflag[k] = (kind[k] >> 2) & 1;
             const int false_overlap_flag = S.ibuf[6] ? -1 : 0;
             if (max_overlap > 0) { const int key = S.ibuf[5]; S.psr_temp[0] = key / prc; S.psr_temp[1] = key - (key / prc) * prc; }
             if ((false_overlap_flag == 0 && max_overlap >= ot) || (false_overlap_flag == -1 && max_overlap >= 2 * ot)) { ret_v[0] = max_overlap; ret_v[1] = 0; }
@@ -638,7 +677,8 @@ FIG_D void fig_detect_overlap_par(FigEng &E, const int *pflag, int stride, int g
         FIG_SYNC();
         return;
     }
-    if (E.tid == 0) { for (int k = 0; k < prc; k++) E.scr.smflag[k] = (kind[k] >> 2) & 1; ret_v[0] = 0; ret_v[1] = 0; }
+    for (int k = E.tid; k < prc; k += E.nt) E.scr.smflag[k] = (kind[k] >> 2) & 1;
+    if (E.tid == 0) { ret_v[0] = 0; ret_v[1] = 0; }
     FIG_SYNC();
 }
 
