@@ -679,7 +679,7 @@ static int run_class_parallel(fig_ctx *ctx, const fig_ctx::Cls &c, FigLane &ln) 
     const int capacity = std::max(1, c.capacity);      // workgroups the device holds for this class (not capped by the gap count)
     const bool log = getenv("FIG_SCHED_LOG") != nullptr;
     const int minc = getenv("FIG_MIN_CHUNK") ? std::max(1, atoi(getenv("FIG_MIN_CHUNK"))) : 16;      // candidates per gap and round, at least
-    const double ipw_base = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : 12.0;  // items per resident workgroup and round (measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
+    const double ipw_base = getenv("FIG_ITEMS_PER_WG") ? std::max(1.0, atof(getenv("FIG_ITEMS_PER_WG"))) : (ctx->dm.unmapped ? 12.0 : 6.0);  // items per resident workgroup and round (partial-mode pass, 8 192 gaps: 6 -> 4 052 gaps/s, 12 -> 3 887, 24 -> 3 875, 48 -> 3 668: shorter rounds discard fewer candidates past an early stop; unmapped, measured on the bench batch: 4 -> 34.4 s, 8 -> 29.7, 12 -> 29.1, 16 -> 29.2 per step)
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_start = now();
     double t_prev = now(); int round = 0, last_items = 0, last_active = 0, last_chunk = 0, n_active_max = 0;
