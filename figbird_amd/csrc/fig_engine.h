@@ -435,6 +435,54 @@ FIG_D int fig_from_code_u(fig_gcu8p fl, fig_lcu8p gs, int x, int G, int left, in
 // Accessors of the extended table (generic pointers; the hot loops use the typed LDS form).
 #define FIG_PQ(E, b, x) ((E).pq[(long long)(b) * (E).ncolE + (x) + (E).xoff])
 #define FIG_Q4(E, x) ((E).q4[(x) + (E).xoff])
+// The same accessors on typed views, selected by E.pq_lds (wave-uniform): ds_* / global_* instead of FLAT instructions in the
+// per-candidate and per-call table code (initialize, computeProbsGap, computeErrorProbsGap, update_partial_prob).
+#ifdef FIG_EMU
+FIG_D void fig_pq_set(const FigEng &E, int b, int x, FigPQ v) { FIG_PQ(E, b, x) = v; }
+FIG_D FigPQ fig_pq_get(const FigEng &E, int b, int x) { return FIG_PQ(E, b, x); }
+FIG_D void fig_pq_set_p(const FigEng &E, int b, int x, double v) { FIG_PQ(E, b, x).p = v; }
+FIG_D void fig_pq_set_q(const FigEng &E, int b, int x, double v) { FIG_PQ(E, b, x).q = v; }
+FIG_D double fig_pq_get_p(const FigEng &E, int b, int x) { return FIG_PQ(E, b, x).p; }
+FIG_D void fig_q4_set(const FigEng &E, int x, double v) { FIG_Q4(E, x) = v; }
+FIG_D double fig_q4_get(const FigEng &E, int x) { return FIG_Q4(E, x); }
+#else
+typedef double fig_d2v __attribute__((ext_vector_type(2)));          // one {p, q} entry as a 16-byte vector (ds_read/write_b128, global dwordx4)
+typedef fig_d2v __attribute__((address_space(3))) *fig_ld2p;
+typedef fig_d2v __attribute__((address_space(1))) *fig_gd2p;
+typedef double __attribute__((address_space(3))) *fig_ldp;
+FIG_D void fig_pq_set(const FigEng &E, int b, int x, FigPQ v) {
+    const long long i = (long long)b * E.ncolE + x + E.xoff;
+    fig_d2v t; t.x = v.p; t.y = v.q;
+    if (E.pq_lds) ((fig_ld2p)(fig_lds + E.off_pq))[i] = t; else ((fig_gd2p)E.pq)[i] = t;
+}
+FIG_D FigPQ fig_pq_get(const FigEng &E, int b, int x) {
+    const long long i = (long long)b * E.ncolE + x + E.xoff;
+    fig_d2v t;
+    if (E.pq_lds) t = ((fig_ld2p)(fig_lds + E.off_pq))[i]; else t = ((fig_gd2p)E.pq)[i];
+    FigPQ v; v.p = t.x; v.q = t.y;
+    return v;
+}
+FIG_D void fig_pq_set_p(const FigEng &E, int b, int x, double v) {
+    const long long i = (long long)b * E.ncolE + x + E.xoff;
+    if (E.pq_lds) ((fig_ldp)(fig_lds + E.off_pq))[2 * i] = v; else ((fig_gdp)(double *)E.pq)[2 * i] = v;
+}
+FIG_D void fig_pq_set_q(const FigEng &E, int b, int x, double v) {
+    const long long i = (long long)b * E.ncolE + x + E.xoff;
+    if (E.pq_lds) ((fig_ldp)(fig_lds + E.off_pq))[2 * i + 1] = v; else ((fig_gdp)(double *)E.pq)[2 * i + 1] = v;
+}
+FIG_D double fig_pq_get_p(const FigEng &E, int b, int x) {
+    const long long i = (long long)b * E.ncolE + x + E.xoff;
+    if (E.pq_lds) return ((fig_ldp)(fig_lds + E.off_pq))[2 * i];
+    return ((fig_gdp)(double *)E.pq)[2 * i];
+}
+FIG_D void fig_q4_set(const FigEng &E, int x, double v) {
+    if (E.pq_lds) ((fig_ldp)(fig_lds + E.off_q4))[x + E.xoff] = v; else ((fig_gdp)E.q4)[x + E.xoff] = v;
+}
+FIG_D double fig_q4_get(const FigEng &E, int x) {
+    if (E.pq_lds) return ((fig_ldp)(fig_lds + E.off_q4))[x + E.xoff];
+    return ((fig_gdp)E.q4)[x + E.xoff];
+}
+#endif
 
 // Flank columns of the extended table for the current window (G, left, right):
 //   x in [-left, 0)      left-flank base at gapStart+x          -> one-hot / N rows of FP,FQ
@@ -452,8 +500,8 @@ FIG_D void fig_build_flank_pq(FigEng &E) {
         int c;
         if (x < 0) c = (-x <= left) ? fig_flank_l(E, -x) : 5;
         else c = (x - G < right) ? fig_flank_r(E, x - G) : 5;
-        for (int b = 0; b < 4; b++) { FigPQ v; v.p = S.FP[c][b]; v.q = S.FQ[c][b]; FIG_PQ(E, b, x) = v; }
-        FIG_Q4(E, x) = S.FQ[c][4];
+        for (int b = 0; b < 4; b++) { FigPQ v; v.p = S.FP[c][b]; v.q = S.FQ[c][b]; fig_pq_set(E, b, x, v); }
+        fig_q4_set(E, x, S.FQ[c][4]);
     }
 }
 
@@ -474,8 +522,8 @@ FIG_D void fig_compute_probs(FigEng &E) {
         for (int j = 0; j < 5; j++) {
             double sum = 0;
             for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
-            if (j < 4) { FigPQ v; v.p = pr[j]; v.q = sum; FIG_PQ(E, j, x) = v; }
-            else FIG_Q4(E, x) = sum;
+            if (j < 4) { FigPQ v; v.p = pr[j]; v.q = sum; fig_pq_set(E, j, x, v); }
+            else fig_q4_set(E, x, sum);
         }
     }
     fig_build_flank_pq(E);
@@ -485,11 +533,11 @@ FIG_D void fig_compute_errprobs_only(FigEng &E) {
     const double *T = E.M->T;
     for (int x = E.tid; x < n; x += E.nt) {
         double pr[4];
-        for (int j = 0; j < 4; j++) pr[j] = FIG_PQ(E, j, x).p;
+        for (int j = 0; j < 4; j++) pr[j] = fig_pq_get_p(E, j, x);
         for (int j = 0; j < 5; j++) {
             double sum = 0;
             for (int k = 0; k < 4; k++) { if (j == k) continue; sum += pr[k] * T[k * 5 + j]; }
-            if (j < 4) FIG_PQ(E, j, x).q = sum; else FIG_Q4(E, x) = sum;
+            if (j < 4) fig_pq_set_q(E, j, x, sum); else fig_q4_set(E, x, sum);
         }
     }
     fig_build_flank_pq(E);

@@ -65,8 +65,8 @@ FIG_D double fig_estep_chain(FigEng &E, double p, int o, int len, int j0, int j1
         if (x < -left) continue;
         int b = E.rb[j];
         int k = rev ? len - 1 - j : j;
-        if (b < 4) { FigPQ v = FIG_PQ(E, b, x); p *= (v.p * ome[k] + e[k] * v.q); }
-        else p *= (e[k] * FIG_Q4(E, x));
+        if (b < 4) { FigPQ v = fig_pq_get(E, b, x); p *= (v.p * ome[k] + e[k] * v.q); }
+        else p *= (e[k] * fig_q4_get(E, x));
     }
     return p;
 }
@@ -230,7 +230,7 @@ FIG_D bool fig_update_partial_prob_cols(FigEng &E, int gaplen) {
         if (c2 > max_val) { max_val = c2; max_index = 2; }
         if (c3 > max_val) { max_val = c3; max_index = 3; }
         E.scr.colchar[j] = (unsigned char)max_index;
-        FIG_PQ(E, 0, j).p = (double)c0 / total; FIG_PQ(E, 1, j).p = (double)c1 / total; FIG_PQ(E, 2, j).p = (double)c2 / total; FIG_PQ(E, 3, j).p = (double)c3 / total;
+        fig_pq_set_p(E, 0, j, (double)c0 / total); fig_pq_set_p(E, 1, j, (double)c1 / total); fig_pq_set_p(E, 2, j, (double)c2 / total); fig_pq_set_p(E, 3, j, (double)c3 / total);
         // partial_left / partial_right (:2062-2079: one pass over the columns, `i <= left_max - 5` -> left, else `i >= right_min + 5`
         // -> right, 99 characters each at most) are two contiguous column ranges: every column writes its own character
         if (j <= left_max - 5) { if (j < 99) S.partial_left[j] = (unsigned char)max_index; }
@@ -290,7 +290,7 @@ FIG_D void fig_update_partial_prob(FigEng &E, int gaplen) {
         int total = 0, max_index = 0, max_val = -1;
         for (int k = 0; k < 4; k++) { int v = E.scr.pc[k * cg + i]; total += v; if (v > max_val) { max_val = v; max_index = k; } }
         E.scr.colchar[i] = (unsigned char)max_index;
-        for (int k = 0; k < 4; k++) FIG_PQ(E, k, i).p = (double)E.scr.pc[k * cg + i] / total;
+        for (int k = 0; k < 4; k++) fig_pq_set_p(E, k, i, (double)E.scr.pc[k * cg + i] / total);
     }
     FIG_SYNC();
     if (E.tid == 0) {
