@@ -103,6 +103,13 @@ def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) ->
             rc = 1
         if fdist.all_status_max(rc, dev) != 0:
             return 1
+        # The gather's own collective cannot be guarded (a rank that never enters it leaves the others waiting), but everything
+        # this rank does before entering it -- taking the draw planes, packing -- happens inside all_gather_packed before its
+        # first collective call, so a rank that fails there is reported through the status exchange below instead of a hang:
+        # the ranks agree first that all of them hold a result to pack.
+        prc = 0 if (res is not None and res.draw is not None) else 1
+        if fdist.all_status_max(prc, dev) != 0:
+            return 1
         dpos, disz, dlen = res.draw
         out = fdist.all_gather_packed(mine, res, n, device=dev, extras=[dlen, dpos, disz])
         wrc = 0
@@ -144,6 +151,8 @@ def run(argv15, backend=None, lib_path=None, device_index=None, verbose=True) ->
             wrc = 1
         return 1 if fdist.all_status_max(wrc, dev) != 0 else 0        # doubles as the closing barrier
     finally:
+        if eng is not None:
+            eng.close()                  # idempotent: also reached on the early returns above
         host.fighost_run_close(h)
         if own_pg:
             dist.destroy_process_group()
